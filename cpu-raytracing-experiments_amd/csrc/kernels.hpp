@@ -1,0 +1,627 @@
+// kernels.hpp — HIP kernels of the wavefront path tracer (gfx950 / CDNA4, wave64).
+//
+// One Renderer::Accumulate() call of the reference (Renderer.hpp:73-434) runs a 256-ray stream per
+// 16x16 tile through raygen -> [intersect -> closest-hit shade -> sort -> NEE -> shadow trace ->
+// emissive -> BRDF sample/RR/compaction -> miss -> accumulate] on one CPU thread.  Here the same
+// path state is a set of SoA ray streams in HBM spanning every pixel this GPU owns times the
+// accumulations in flight, and one bounce is three kernels:
+//
+//   k_trace_closest   Traverse            (BVH.hpp:309-360)     reads p,dir           writes tfar,primID
+//   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into
+//                     the next stream and NEE candidates into the shadow stream with wave64
+//                     ballot + mbcnt prefix sums (one atomic per wave per stream)
+//   k_trace_shadow    Traverse_shadow     (BVH.hpp:362-404) + Renderer.hpp:304-314 and the deferred
+//                     radiance finalisation ((R + unoccluded NEE) + emissive), in the reference's add order
+//
+// Per-path results do not depend on stream slot or scheduling: every random draw is re-derived from
+// (accumulations, seed[pixel], bounce) (Renderer.hpp:107,117,255,362), which is what lets the
+// wavefront reorder rays freely and still reproduce the reference bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_math.hpp"
+
+namespace mirt {
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kTraceBlock = 512;           // trace kernels: bigger workgroups amortise the LDS staging of the BVH
+constexpr uint32_t kLeafBit = 0x80000000u;      // child reference flag (bvh_layout.hpp)
+constexpr uint32_t kTileSize = 256;
+constexpr uint32_t kTileRoot = 16;
+constexpr uint32_t kStack = 64;                 // Stack<StackFrame,64>, BVH.hpp:321
+constexpr uint32_t kDestAccum = 0x80000000u;    // shadow-entry destination flag: accumulator instead of stream slot
+
+struct SceneDev {
+	const float4* recs;         // GPU-internal child-pair records, 4 float4 each, breadth-first (bvh_layout.hpp)
+	const float4* spheres;      // acceleration_structure.prims (BVH order): {pos.xyz, radius_sq}
+	const int32_t* prim_mat;    //   "  material_ID
+	const float4* geom;         // scene.geometry (authoring order): {pos.xyz, radius_sq}   (NEE, Renderer.hpp:262)
+	const int32_t* geom_mat;
+	const float4* mat_albedo;   // scene.material[].albedo
+	const float4* mat_emission; // scene.material[].emission
+	const int32_t* lights;      // lighting_acceleration.prims (geometry-order indices)
+	const float4* hdri;         // sky.hdri_data RGBA
+	uint32_t n_spheres, n_recs, n_mat, n_lights;
+	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
+	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
+	float ambient[3];
+	int32_t hdri_w, hdri_h;
+	float hdri_fw, hdri_fh;
+	uint32_t has_ambient;       // Renderer.hpp:79
+	uint32_t use_bvh;
+};
+
+// RayStream<>::Buffer, DataStreams.hpp:75-88 — one SoA plane per member, `capacity` rays each.
+struct StreamBuf {
+	float *px, *py, *pz, *dx, *dy, *dz;
+	float *tr, *tg, *tb;        // throughput
+	float *rr, *rg, *rb;        // radiance
+	float *pdf;
+	uint32_t* path;             // (batch slot << 24) | local pixel index (tile_local*256 + ID); stands in for pixelID + seed[]
+};
+// RayStream<>::ShadowStream, DataStreams.hpp:113-126, plus the deferred-add operands.
+struct ShadowBuf {
+	float *px, *py, *pz, *dx, *dy, *dz, *tfar;
+	float *sr, *sg, *sb;        // NEE radiance carried by the shadow ray
+	float *rr, *rg, *rb;        // path radiance before this bounce's adds
+	float *er, *eg, *eb;        // emissive add of this bounce (0 if none)
+	uint32_t* dest;             // next-stream slot, or kDestAccum | path id
+};
+struct FrameParams {
+	CameraParams cam;
+	uint32_t h_tiles;           // Renderer.hpp:59
+	uint32_t first_tile;        // first global LaunchIndex owned by this context
+	uint32_t n_pix;             // local pixels = local tiles * 256
+	uint32_t acc_base;          // `accumulations` before this batch
+	uint32_t batch_n;           // accumulations in flight (each lands in its own bucket)
+	uint32_t max_bounces;
+	uint32_t buckets;
+	uint32_t mis;               // MIS && light_count > 0 (Q12 guard)
+	uint32_t n_lights;
+};
+struct DevCounters {
+	unsigned long long rays, shadow_rays, nodes, spheres, shadow_nodes, shadow_spheres, terminated, dropped;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+MIRT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+MIRT_DI uint32_t mask_rank(unsigned long long m) {            // set bits of m below this lane
+	return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+// Stream compaction slot for lanes with `flag`: one atomicAdd per wave (call with the whole wave converged).
+MIRT_DI uint32_t wave_append(bool flag, uint32_t* counter) {
+	const unsigned long long m = __ballot(flag);
+	uint32_t base = 0;
+	if (m != 0ull) {
+		if (lane_id() == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
+		base = __builtin_amdgcn_readfirstlane(base);
+	}
+	return base + mask_rank(m);
+}
+MIRT_DI void wave_count(bool flag, unsigned long long* counter) {
+	const unsigned long long m = __ballot(flag);
+	if (m != 0ull && lane_id() == 0) atomicAdd(counter, static_cast<unsigned long long>(__popcll(m)));
+}
+MIRT_DI void wave_sum(uint32_t v, unsigned long long* counter) {
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	if (lane_id() == 0 && v) atomicAdd(counter, static_cast<unsigned long long>(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Intersection arithmetic
+// ------------------------------------------------------------------------------------------------
+// 8-ray x 1-sphere AVX2 body of intersect_prims, BVH.hpp:251-267, one lane per ray: the FMA chain as written
+// there; accept iff dist < tfar, sign(dist) clear, sign(sqrt(disc)) clear (= disc not negative / -0).
+MIRT_DI void sphere_closest(float4 s, int32_t prim, float px, float py, float pz, float dx, float dy, float dz,
+                            float& tfar, int32_t& primID) {
+	float tx = s.x - px;
+	float b = dx * tx;
+	float disc = __builtin_fmaf(-tx, tx, s.w);
+	float ty = s.y - py;
+	b = __builtin_fmaf(dy, ty, b);
+	disc = __builtin_fmaf(-ty, ty, disc);
+	float tz = s.z - pz;
+	b = __builtin_fmaf(dz, tz, b);
+	disc = __builtin_fmaf(-tz, tz, disc);
+	disc = __builtin_fmaf(b, b, disc);
+	if (__float_as_uint(disc) & 0x80000000u) return;
+	float sq = __builtin_sqrtf(disc);
+	float dist = b - sq;
+	if (__float_as_uint(dist) & 0x80000000u) dist = b + sq;
+	if ((dist < tfar) && !(__float_as_uint(dist) & 0x80000000u)) { tfar = dist; primID = prim; }
+}
+// intersect_prims_shadow, BVH.hpp:294-300 (scalar, unfused)
+MIRT_DI bool sphere_occludes(float4 s, float px, float py, float pz, float dx, float dy, float dz, float tfar) {
+	f3 P{ s.x - px, s.y - py, s.z - pz };
+	float b = dot3(f3{ dx, dy, dz }, P);
+	float disc = b * b - dot3(P, P) + s.w;
+	if (disc < 0.0f) return false;
+	disc = __builtin_sqrtf(disc);
+	float dist = (b >= disc ? b - disc : b + disc);
+	if (dist < 0.0f || dist >= tfar) return false;
+	return true;
+}
+// ---- BVH traversal -----------------------------------------------------------------------------
+// Semantics (DESIGN.md "Traversal semantics"): the BVH is a pure acceleration of the reference's shipped
+// brute-force loops (BVH.hpp:312 / :365).  Boxes are conservative (bvh_layout.hpp), the ray interval is
+// [0, tfar], and the closest hit is the lexicographic minimum of (dist, BVH-order prim index) — which is
+// what the ascending strict-'<' scan of intersect_prims returns — so visiting order, pruning and the slab
+// arithmetic cannot change the result.  oracle/oracle.cpp mode 2 is the CPU twin of this routine.
+struct RaySlab { float ix, iy, iz, nx, ny, nz; };
+MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
+	RaySlab s;
+	s.ix = 1.0f / dx; s.iy = 1.0f / dy; s.iz = 1.0f / dz;
+	s.nx = -(px * s.ix); s.ny = -(py * s.iy); s.nz = -(pz * s.iz);
+	return s;
+}
+// fminf/fmaxf lower to v_min_f32 / v_max_f32 (v_min3/v_max3): NaNs from 0*inf slabs are dropped.
+MIRT_DI bool slab_hit(float lx, float hx, float ly, float hy, float lz, float hz, float tfar, float& tnear) {
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fmaxf(__builtin_fminf(lz, hz), 0.0f));
+	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fminf(__builtin_fmaxf(lz, hz), tfar));
+	tnear = tmin;
+	return tmin <= tmax;
+}
+// intersect_prims acceptance made order-independent: candidate against an open tfar, then (dist, index) order.
+MIRT_DI void sphere_closest_tie(float4 s, int32_t prim, float px, float py, float pz, float dx, float dy, float dz,
+                                float& tfar, int32_t& primID) {
+	float t = MIRT_FLT_MAX; int32_t id = -1;
+	sphere_closest(s, prim, px, py, pz, dx, dy, dz, t, id);
+	if (id < 0) return;
+	if (t < tfar || (t == tfar && (primID < 0 || prim < primID))) { tfar = t; primID = prim; }
+}
+
+struct TraceLds { const float4* recs; const float4* spheres; };
+
+template <bool ANYHIT, bool COUNT>
+MIRT_DI bool traverse_bvh(const SceneDev& sc, const TraceLds lds, float px, float py, float pz, float dx, float dy, float dz,
+                          float& tfar, int32_t& primID, uint32_t& n_nodes, uint32_t& n_spheres) {
+	if (sc.n_recs == 0) return false;
+	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
+	uint32_t stack[kStack];
+	uint32_t sp = 0;
+	uint32_t cur = 0;
+	for (;;) {
+		float4 q0, q1, q2, q3;
+		if (cur < sc.lds_recs) { const float4* r = lds.recs + 4u * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+		else { const float4* r = sc.recs + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+		if (COUNT) n_nodes += 2;
+		float ta, tb;
+		bool ha = slab_hit(__builtin_fmaf(q0.x, rs.ix, rs.nx), __builtin_fmaf(q0.z, rs.ix, rs.nx),
+		                   __builtin_fmaf(q1.x, rs.iy, rs.ny), __builtin_fmaf(q1.z, rs.iy, rs.ny),
+		                   __builtin_fmaf(q2.x, rs.iz, rs.nz), __builtin_fmaf(q2.z, rs.iz, rs.nz), tfar, ta);
+		bool hb = slab_hit(__builtin_fmaf(q0.y, rs.ix, rs.nx), __builtin_fmaf(q0.w, rs.ix, rs.nx),
+		                   __builtin_fmaf(q1.y, rs.iy, rs.ny), __builtin_fmaf(q1.w, rs.iy, rs.ny),
+		                   __builtin_fmaf(q2.y, rs.iz, rs.nz), __builtin_fmaf(q2.w, rs.iz, rs.nz), tfar, tb);
+		const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+		// hit leaf children are resolved on the spot (no stack traffic; shrinks tfar before descending)
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const uint32_t c = k ? c1 : c0;
+			const bool h = k ? hb : ha;
+			if (h && (c & kLeafBit)) {
+				const uint32_t first = c & 0xffffffu, count = ((c >> 24) & 0x7fu) + 1u;
+				for (uint32_t p = first; p < first + count; p++) {
+					if (COUNT) n_spheres++;
+					const float4 s = (p < sc.lds_spheres) ? lds.spheres[p] : sc.spheres[p];
+					if (ANYHIT) { if (sphere_occludes(s, px, py, pz, dx, dy, dz, tfar)) return true; }
+					else sphere_closest_tie(s, static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
+				}
+			}
+		}
+		ha = ha && !(c0 & kLeafBit); hb = hb && !(c1 & kLeafBit);
+		if (!ANYHIT) { ha = ha && ta <= tfar; hb = hb && tb <= tfar; }          // re-check against the shrunken tfar
+		if (ha && hb) {
+			const bool a_first = ANYHIT ? true : (ta <= tb);
+			if (sp < kStack) stack[sp++] = a_first ? c1 : c0;                     // depth < 64 is validated on the host
+			cur = a_first ? c0 : c1;
+			continue;
+		}
+		if (ha) { cur = c0; continue; }
+		if (hb) { cur = c1; continue; }
+		if (sp == 0) break;
+		cur = stack[--sp];
+	}
+	return false;
+}
+
+// Brute force over all prims (the reference as shipped, BVH.hpp:312 / :365), sphere packets staged
+// through LDS one chunk at a time by the whole workgroup.
+constexpr uint32_t kBruteChunk = 1024;   // 16 KiB of float4
+template <bool ANYHIT, bool COUNT>
+MIRT_DI bool traverse_brute(const SceneDev& sc, float4* lds, bool active, float px, float py, float pz, float dx, float dy, float dz,
+                            float& tfar, int32_t& primID, uint32_t& n_spheres) {
+	bool occluded = false;
+	for (uint32_t base = 0; base < sc.n_spheres; base += kBruteChunk) {
+		const uint32_t cnt = min(kBruteChunk, sc.n_spheres - base);
+		__syncthreads();
+		for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) lds[j] = sc.spheres[base + j];
+		__syncthreads();
+		if (active && !(ANYHIT && occluded)) {
+			for (uint32_t j = 0; j < cnt; j++) {
+				if (COUNT) n_spheres++;
+				const float4 s = lds[j];
+				if (ANYHIT) { if (sphere_occludes(s, px, py, pz, dx, dy, dz, tfar)) { occluded = true; break; } }
+				else sphere_closest(s, static_cast<int32_t>(base + j), px, py, pz, dx, dy, dz, tfar, primID);
+			}
+		}
+	}
+	return occluded;
+}
+
+// Dynamic LDS of the trace kernels: [records 0..lds_recs) | spheres 0..lds_spheres)] for the BVH path,
+// or one kBruteChunk sphere buffer for the brute-force path.
+MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds) {
+	const uint32_t nq = sc.lds_recs * 4u;
+	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[j] = sc.recs[j];
+	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sc.spheres[j];
+	__syncthreads();
+	return TraceLds{ lds, lds + nq };
+}
+
+// ------------------------------------------------------------------------------------------------
+// RAY GENERATION — Renderer.hpp:97-127 (stream init is implicit: radiance 0 / throughput 1 are
+// supplied by k_shade<FIRST>, so only p, dir and the path id are written)
+// ------------------------------------------------------------------------------------------------
+MIRT_DI uint32_t path_seed(const FrameParams& fp, uint32_t pix) {      // seed[ID], Renderer.hpp:107 (wraps like the int32 cast)
+	return (fp.first_tile * kTileSize + pix) * (fp.max_bounces * 2u + 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out, uint32_t* stream_count) {
+	const uint32_t total = fp.n_pix * fp.batch_n;
+	if (blockIdx.x == 0 && threadIdx.x == 0) stream_count[0] = total;
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+		const uint32_t slot = i / fp.n_pix;
+		const uint32_t pix = i - slot * fp.n_pix;
+		const uint32_t tile = fp.first_tile + (pix >> 8);
+		const uint32_t ID = pix & 255u;
+		const int32_t x = static_cast<int32_t>(kTileRoot * (tile % fp.h_tiles) + (ID & 15u));
+		const int32_t y = static_cast<int32_t>(kTileRoot * (tile / fp.h_tiles) + (ID >> 4));
+		const uint32_t acc = fp.acc_base + slot + 1u;                       // ++accumulations, Renderer.hpp:74
+		uint32_t rng = hash_2d(acc, path_seed(fp, pix));
+		const float s0 = rand_unit_float(rng);
+		const float s1 = rand_unit_float(rng);
+		const f3 d = camera_ray_dir(fp.cam, x, y, s0, s1);
+		out.px[i] = fp.cam.pos[0]; out.py[i] = fp.cam.pos[1]; out.pz[i] = fp.cam.pos[2];
+		out.dx[i] = d.x; out.dy[i] = d.y; out.dz[i] = d.z;
+		out.path[i] = (slot << 24) | pix;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// INTERSECTION — Traverse, BVH.hpp:309-360
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
+                                                               const uint32_t* __restrict__ count_ptr, DevCounters* ctr) {
+	extern __shared__ float4 lds[];
+	const uint32_t n = *count_ptr;
+	if (n == 0) return;
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, static_cast<unsigned long long>(n));
+	if (blockIdx.x * kTraceBlock >= n) return;                       // whole workgroup idle: skip the staging too
+	uint32_t c_nodes = 0, c_spheres = 0;
+	TraceLds tl{ lds, lds };
+	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+		const uint32_t i = base + threadIdx.x;
+		const bool active = i < n;
+		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
+		if (active) { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
+		float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
+		int32_t prim = -1;
+		if (sc.use_bvh) {
+			if (active) traverse_bvh<false, COUNT>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
+		} else {
+			traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
+		}
+		if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
+	}
+	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Accumulator addressing — AccumulationTile<k>, Renderer.hpp:43-46,84: [tile][bucket][r,g,b][256]
+// ------------------------------------------------------------------------------------------------
+MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) {
+	const uint32_t slot = (path >> 24) & 0x7fu;
+	const uint32_t pix = path & 0xffffffu;
+	const uint32_t bucket = (fp.acc_base + slot + 1u) % fp.buckets;         // Renderer.hpp:82
+	return (static_cast<size_t>(pix >> 8) * fp.buckets + bucket) * 3u * kTileSize + (pix & 255u);
+}
+MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, float g, float b) {     // Renderer.hpp:427-429
+	// (pixel, bucket) is unique within a batch and batches are stream-ordered: plain read-modify-write, no atomics,
+	// and each bucket sees its adds in accumulation order exactly like the reference.
+	accum[idx] += r; accum[idx + kTileSize] += g; accum[idx + 2 * kTileSize] += b;
+}
+
+// Sky::operator(), Primitives.hpp:35-46
+MIRT_DI f3 sky_eval(const SceneDev& sc, float x, float y, float z) {
+	const float ex = sc.hdri_fw * (0.5f + MIRT_INV_TWO_PI * fast_atan2(z, x));
+	const float ey = sc.hdri_fh * (0.5f - MIRT_INV_PI * fast_asin(y));
+	const float4 t = sc.hdri[static_cast<int32_t>(ey) * sc.hdri_w + static_cast<int32_t>(ex)];
+	return { t.x * sc.ambient[0], t.y * sc.ambient[1], t.z * sc.ambient[2] };
+}
+
+// ------------------------------------------------------------------------------------------------
+// SHADE — closest-hit shader, NEE, emissive, BRDF sample + Russian roulette + compaction, miss, accumulate
+// (Renderer.hpp:169-431).  FIRST = bounce 0: radiance 0, throughput 1 (Renderer.hpp:98-101) without reading them.
+// ------------------------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
+                                                  const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
+                                                  uint32_t* stream_count, uint32_t* shadow_count, float* __restrict__ accum, DevCounters* ctr) {
+	const uint32_t n = stream_count[bounce];
+	uint32_t* next_count = &stream_count[bounce + 1];
+	uint32_t* sh_count = &shadow_count[bounce];
+	const bool last_bounce = !(bounce < fp.max_bounces - 1u);                 // Renderer.hpp:358
+	const float light_selection_pdf = 1.0f / static_cast<float>(fp.n_lights);  // Renderer.hpp:78
+
+	for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+		const uint32_t i = base + threadIdx.x;
+		const bool active = i < n;
+		bool survive = false, has_shadow = false, terminated = false, dropped = false;
+		uint32_t path = 0;
+		f3 P{0, 0, 0}, ndir{0, 0, 0}, L{0, 0, 0}, srad{0, 0, 0}, E{0, 0, 0};
+		f3 R{0.0f, 0.0f, 0.0f}, thr{1.0f, 1.0f, 1.0f};
+		float npdf = 0.0f, light_distance = 0.0f;
+
+		if (active) {
+			path = in.path[i];
+			const f3 D{ in.dx[i], in.dy[i], in.dz[i] };
+			float pdf_in = 0.0f;
+			if (!FIRST) {
+				R = { in.rr[i], in.rg[i], in.rb[i] };
+				thr = { in.tr[i], in.tg[i], in.tb[i] };
+				pdf_in = in.pdf[i];
+			}
+			const int32_t prim = prim_in[i];
+			if (prim < 0) {
+				// MISS SHADER, Renderer.hpp:408-420 (Q10: throughput.r scales all three channels)
+				terminated = true;
+				if (sc.has_ambient) {
+					const f3 sky = sky_eval(sc, D.x, D.y, D.z);
+					R.x += thr.x * sky.x; R.y += thr.x * sky.y; R.z += thr.x * sky.z;
+				}
+			} else if (last_bounce) {
+				dropped = true;                                                   // Q5: still alive after the last bounce -> never accumulated
+			} else {
+				// CLOSEST HIT SHADER, Renderer.hpp:169-214
+				const float depth = tfar_in[i];
+				const float4 hs = sc.spheres[prim];
+				const int32_t mat = sc.prim_mat[prim];
+				const f3 O{ in.px[i], in.py[i], in.pz[i] };
+				const f3 hit{ O.x + D.x * depth, O.y + D.y * depth, O.z + D.z * depth };
+				f3 N = normalize3(f3{ hit.x - hs.x, hit.y - hs.y, hit.z - hs.z });
+				if (dot3(N, D) >= 0.0f) N = f3{ -N.x, -N.y, -N.z };
+				const quat T = tangent_space(N);
+				const f3 Vl = to_local(T, f3{ -D.x, -D.y, -D.z });
+				P = { hit.x + N.x * 1e-4f, hit.y + N.y * 1e-4f, hit.z + N.z * 1e-4f };
+				const float4 em = sc.mat_emission[mat];
+				const float4 alb = sc.mat_albedo[mat];
+				const bool is_emissive = max_sel(em.x, max_sel(em.y, em.z)) > MIRT_FLT_EPSILON;
+				const uint32_t acc = fp.acc_base + (path >> 24) + 1u;
+				const uint32_t seed = path_seed(fp, path & 0xffffffu);
+
+				// NEXT EVENT ESTIMATION, Renderer.hpp:247-298
+				if (fp.mis) {
+					uint32_t rng = hash_2d(acc, seed + bounce * 2u);
+					const float u0 = rand_unit_float(rng);
+					const float u1 = rand_unit_float(rng);
+					const int32_t selected = static_cast<int32_t>(rand_bounded_int(rng, fp.n_lights));
+					const int32_t light_primID = sc.lights[selected];
+					const float4 lp = sc.geom[light_primID];
+					do {
+						if (light_primID == prim) break;                             // Q11: geometry-order id vs BVH-order id
+						f3 Wc{ lp.x - P.x, lp.y - P.y, lp.z - P.z };
+						const float center_dist2 = dot3(Wc, Wc);
+						if (center_dist2 <= lp.w) break;
+						const float center_dist = __builtin_sqrtf(center_dist2);
+						{ const float inv = 1.0f / center_dist; Wc.x *= inv; Wc.y *= inv; Wc.z *= inv; }
+						const float sinThetaMax2 = lp.w / center_dist2;
+						{
+							const float NdotW = (2.0f * T.w) * (Wc.z * T.w + Wc.x * T.y - T.x * Wc.y) - Wc.z;
+							if (NdotW < 0.0f && sinThetaMax2 < NdotW * NdotW) break;
+						}
+						float ldist, lpdf;
+						const f3 Ld = sample_direction_to_sphere(Wc, sinThetaMax2, center_dist, lp.w, u0, u1, ldist, lpdf);
+						const f3 Ll = to_local(T, Ld);
+						if (Ll.z < 0.0f) break;
+						const float4 lem = sc.mat_emission[sc.geom_mat[light_primID]];
+						f3 rad{ lem.x * thr.x, lem.y * thr.y, lem.z * thr.z };
+						{   // Closure<LambertianDiffuse>::eval, DataStreams.hpp:169-172
+							const float f = MIRT_INV_PI * max_sel(0.0f, Ll.z);
+							rad.x *= alb.x * f; rad.y *= alb.y * f; rad.z *= alb.z * f;
+						}
+						lpdf *= light_selection_pdf;
+						const float brdf_pdf = MIRT_INV_PI * max_sel(0.0f, Ll.z);  // DataStreams.hpp:173-176
+						const float w = powerHeuristic_over_f(lpdf, brdf_pdf);
+						rad.x *= w; rad.y *= w; rad.z *= w;
+						if (max_sel(max_sel(rad.x, rad.y), rad.z) <= 0.0f) break;
+						has_shadow = true; L = Ld; light_distance = ldist; srad = rad;
+					} while (false);
+				}
+				// EMISSIVE PRIMITIVE HIT, Renderer.hpp:319-353
+				if (is_emissive) {
+					if (fp.mis && bounce > 0) {
+						const float radius2 = hs.w;
+						const float center_dist2 = depth * (depth + Vl.z * (2.0f * __builtin_sqrtf(radius2))) + radius2;
+						const float weight = powerHeuristic(pdf_in, light_selection_pdf * spherePdf(radius2, center_dist2));
+						E = { (thr.x * weight) * em.x, (thr.y * weight) * em.y, (thr.z * weight) * em.z };
+					} else {
+						E = { em.x, em.y, em.z };                                   // Q9: no throughput
+					}
+				}
+				// BRDF SAMPLING - BOUNCE, Renderer.hpp:357-404
+				{
+					uint32_t rng = hash_2d(acc, seed + bounce * 2u + 1u);
+					const float b0 = rand_unit_float(rng);
+					const float b1 = rand_unit_float(rng);
+					f3 sd = hemisphere(b0, b1);                                     // Closure::sample, DataStreams.hpp:177-181
+					thr = { thr.x * alb.x, thr.y * alb.y, thr.z * alb.z };
+					const float q = 1.0f - max_sel(thr.x, max_sel(thr.y, thr.z));
+					if (rand_unit_float(rng) < q) {
+						terminated = true;                                          // Russian roulette, Renderer.hpp:377-383
+					} else {
+						const float inv = 1.0f / max_sel(MIRT_FLT_EPSILON, 1.0f - q);
+						thr = { thr.x * inv, thr.y * inv, thr.z * inv };
+						ndir = to_world(T, sd);
+						npdf = MIRT_INV_PI * max_sel(0.0f, ndir.z);                 // Q8: pdf of the world-space direction
+						survive = true;
+					}
+				}
+			}
+		}
+		// ---- stream compaction: wave64 ballot + mbcnt prefix, one atomic per wave and stream ----
+		const uint32_t slot = wave_append(survive, next_count);
+		const uint32_t sslot = wave_append(has_shadow, sh_count);
+		if (survive) {
+			out.px[slot] = P.x; out.py[slot] = P.y; out.pz[slot] = P.z;
+			out.dx[slot] = ndir.x; out.dy[slot] = ndir.y; out.dz[slot] = ndir.z;
+			out.tr[slot] = thr.x; out.tg[slot] = thr.y; out.tb[slot] = thr.z;
+			out.pdf[slot] = npdf;
+			out.path[slot] = path;
+		}
+		if (has_shadow) {
+			// radiance is finalised by k_trace_shadow once occlusion is known: (R + unoccluded NEE) + E
+			sh.px[sslot] = P.x; sh.py[sslot] = P.y; sh.pz[sslot] = P.z;
+			sh.dx[sslot] = L.x; sh.dy[sslot] = L.y; sh.dz[sslot] = L.z;
+			sh.tfar[sslot] = light_distance;
+			sh.sr[sslot] = srad.x; sh.sg[sslot] = srad.y; sh.sb[sslot] = srad.z;
+			sh.rr[sslot] = R.x; sh.rg[sslot] = R.y; sh.rb[sslot] = R.z;
+			sh.er[sslot] = E.x; sh.eg[sslot] = E.y; sh.eb[sslot] = E.z;
+			sh.dest[sslot] = survive ? slot : (kDestAccum | path);
+		} else if (survive || terminated) {
+			const f3 Rf{ R.x + E.x, R.y + E.y, R.z + E.z };                       // E is +0 when the hit is not emissive (exact no-op)
+			if (survive) { out.rr[slot] = Rf.x; out.rg[slot] = Rf.y; out.rb[slot] = Rf.z; }
+			else accumulate_add(accum, accum_index(fp, path), Rf.x, Rf.y, Rf.z);   // ACCUMULATION, Renderer.hpp:424-430
+		}
+		wave_count(terminated && !has_shadow, &ctr->terminated);
+		wave_count(dropped, &ctr->dropped);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// SHADOW RAY TRACING + accumulation — Traverse_shadow (BVH.hpp:362-404), Renderer.hpp:304-314
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, ShadowBuf sh, StreamBuf out, uint32_t bounce,
+                                                              const uint32_t* __restrict__ shadow_count, float* __restrict__ accum, DevCounters* ctr) {
+	extern __shared__ float4 lds[];
+	const uint32_t n = shadow_count[bounce];
+	if (n == 0) return;
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(n));
+	if (blockIdx.x * kTraceBlock >= n) return;
+	uint32_t c_nodes = 0, c_spheres = 0;
+	TraceLds tl{ lds, lds };
+	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+		const uint32_t i = base + threadIdx.x;
+		const bool active = i < n;
+		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
+		if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
+		bool occluded = false;
+		int32_t dummy = -1;
+		if (sc.use_bvh) {
+			if (active) occluded = traverse_bvh<true, COUNT>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres);
+		} else {
+			occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c_spheres);
+		}
+		bool to_accum = false;
+		if (active) {
+			f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
+			if (!occluded) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }     // Renderer.hpp:307-311
+			R.x += sh.er[i]; R.y += sh.eg[i]; R.z += sh.eb[i];                        // Renderer.hpp:339-341 / 348-350
+			const uint32_t dest = sh.dest[i];
+			if (dest & kDestAccum) { to_accum = true; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
+			else { out.rr[dest] = R.x; out.rg[dest] = R.y; out.rb[dest] = R.z; }
+		}
+		wave_count(to_accum, &ctr->terminated);
+	}
+	if (COUNT) { wave_sum(c_nodes, &ctr->shadow_nodes); wave_sum(c_spheres, &ctr->shadow_spheres); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MEDIAN OF MEANS & TONEMAPPING — Renderer::Render, Renderer.hpp:436-478
+// ------------------------------------------------------------------------------------------------
+MIRT_DI float median_k(float* v, uint32_t k) {
+	if (k == 5) return median5(v[0], v[1], v[2], v[3], v[4]);               // the reference network, Sampling.hpp:13-21
+	for (uint32_t a = 1; a < k; a++) {                                      // generalisation (Q19): insertion sort
+		float key = v[a]; int b = static_cast<int>(a) - 1;
+		while (b >= 0 && key < v[b]) { v[b + 1] = v[b]; b--; }
+		v[b + 1] = key;
+	}
+	return (k & 1u) ? v[k / 2] : (v[k / 2 - 1] + v[k / 2]) * 0.5f;
+}
+__global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ accum, float4* __restrict__ fb, uint32_t n_pix, uint32_t first_tile,
+                                                    uint32_t h_tiles, uint32_t width, uint32_t buckets, float scale) {
+	for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < n_pix; pix += gridDim.x * kBlock) {
+		const float* src = accum + static_cast<size_t>(pix >> 8) * buckets * 3u * kTileSize + (pix & 255u);
+		float ch[3];
+		for (uint32_t c = 0; c < 3; c++) {
+			float v[16];
+			for (uint32_t b = 0; b < 16; b++) if (b < buckets) v[b] = src[(static_cast<size_t>(b) * 3u + c) * kTileSize];
+			ch[c] = scale * median_k(v, buckets);                               // Renderer.hpp:453-455
+		}
+		tonemapping(ch[0], ch[1], ch[2]);                                       // Renderer.hpp:461
+		const uint32_t tile = first_tile + (pix >> 8), ID = pix & 255u;
+		const uint32_t x = kTileRoot * (tile % h_tiles) + (ID & 15u);
+		const uint32_t y = kTileRoot * (tile / h_tiles) + (ID >> 4);
+		fb[static_cast<size_t>(y) * width + x] = make_float4(ch[0], ch[1], ch[2], 1.0f);   // Renderer.hpp:447,465
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage-level debug kernels (mirt_debug_*)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTraceBlock) void k_debug_shadow(SceneDev sc, const float* p, const float* d, const float* tfar_in, uint8_t* occ, uint32_t n) {
+	extern __shared__ float4 lds[];
+	uint32_t c0 = 0, c1 = 0;
+	if (blockIdx.x * kTraceBlock >= n) return;
+	TraceLds tl{ lds, lds };
+	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+		const uint32_t i = base + threadIdx.x;
+		const bool active = i < n;
+		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
+		if (active) { px = p[i]; py = p[n + i]; pz = p[2 * n + i]; dx = d[i]; dy = d[n + i]; dz = d[2 * n + i]; tfar = tfar_in[i]; }
+		bool o = false; int32_t dummy = -1;
+		if (sc.use_bvh) { if (active) o = traverse_bvh<true, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1); }
+		else o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
+		if (active) occ[i] = o ? 1 : 0;
+	}
+}
+__global__ __launch_bounds__(kBlock) void k_debug_math(int fn, uint32_t n, const float* in, float* out) {
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+		switch (fn) {
+		case 0: { float s, c; fast_sincos(in[i], s, c); out[i] = s; out[n + i] = c; } break;
+		case 1: out[i] = fast_atan2(in[i], in[n + i]); break;
+		case 2: out[i] = fast_asin(in[i]); break;
+		case 3: out[i] = 1.0f / in[i]; out[n + i] = __builtin_sqrtf(fabs_bits(in[i])); out[2 * n + i] = in[i] / in[n + i]; break;
+		case 4: { f3 h = hemisphere(in[i], in[n + i]); out[i] = h.x; out[n + i] = h.y; out[2 * n + i] = h.z; } break;
+		case 5: {
+			f3 N{ in[i], in[n + i], in[2 * n + i] }, v{ in[3 * n + i], in[4 * n + i], in[5 * n + i] };
+			quat T = tangent_space(N); f3 l = to_local(T, v); f3 w = to_world(T, v);
+			out[i] = T.x; out[n + i] = T.y; out[2 * n + i] = T.z; out[3 * n + i] = T.w;
+			out[4 * n + i] = l.x; out[5 * n + i] = l.y; out[6 * n + i] = l.z;
+			out[7 * n + i] = w.x; out[8 * n + i] = w.y; out[9 * n + i] = w.z;
+		} break;
+		case 6: {
+			f3 Wc{ in[i], in[n + i], in[2 * n + i] };
+			float dist, pdf;
+			f3 Ld = sample_direction_to_sphere(Wc, in[3 * n + i], in[4 * n + i], in[5 * n + i], in[6 * n + i], in[7 * n + i], dist, pdf);
+			out[i] = Ld.x; out[n + i] = Ld.y; out[2 * n + i] = Ld.z; out[3 * n + i] = dist; out[4 * n + i] = pdf;
+		} break;
+		case 7: {
+			uint32_t s = hash_2d(__float_as_uint(in[i]), __float_as_uint(in[n + i]));
+			out[i] = __uint_as_float(s);
+			out[n + i] = rand_unit_float(s); out[2 * n + i] = rand_unit_float(s);
+			uint32_t s2 = s;
+			out[3 * n + i] = rand_unit_float(s);
+			out[4 * n + i] = __uint_as_float(rand_bounded_int(s2, __float_as_uint(in[2 * n + i])));
+		} break;
+		default: break;
+		}
+	}
+}
+
+} // namespace mirt

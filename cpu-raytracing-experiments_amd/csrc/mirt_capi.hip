@@ -1,0 +1,631 @@
+// mirt_capi.hip — C-ABI (include/mirt.h) over the HIP kernels in kernels.hpp.
+//
+// Host-side stand-in for the state Renderer<Policy> keeps (Renderer.hpp:38-49): scene reference,
+// accumulator, width/height, accumulations, h_tiles/v_tiles — with the scene copied to HBM, the
+// accumulator resident in HBM in the reference's AccumulationTile layout, and the per-tile ray
+// streams replaced by one set of frame-wide SoA streams (see kernels.hpp).
+//
+// There is no CPU fallback: every entry point that computes needs a gfx950 device and fails with
+// MIRT_ERR_NO_DEVICE / MIRT_ERR_HIP otherwise.
+#include "../../include/mirt.h"
+#include "kernels.hpp"
+#include "bvh_layout.hpp"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mirt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	hipError_t ensure(size_t want) {
+		if (want <= bytes && ptr) return hipSuccess;
+		if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+		if (want == 0) return hipSuccess;
+		hipError_t e = hipMalloc(&ptr, want);
+		if (e == hipSuccess) bytes = want;
+		return e;
+	}
+	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+	template <class T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+struct TimedLaunch { int klass; hipEvent_t start, stop; };
+
+} // namespace
+
+struct mirt_ctx {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	std::string error;
+
+	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0 };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
+	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
+	uint32_t first_tile = 0, n_tiles = 0;
+	uint32_t accumulations = 0;
+	bool have_scene = false, have_camera = false;
+
+	// scene
+	DeviceBuffer recs, spheres, prim_mat, geom, geom_mat, mat_albedo, mat_emission, lights, hdri;
+	SceneDev scene{};
+	CameraParams camera{};
+	uint32_t trace_lds_bytes = 0;    // dynamic LDS of the BVH trace kernels (staged records + spheres)
+	uint32_t bvh_depth = 0;
+
+	// frame state
+	DeviceBuffer accumulator;        // [local tile][bucket][3][256] f32
+	DeviceBuffer framebuffer;        // width*height float4
+	DeviceBuffer arena;              // ray streams
+	DeviceBuffer counts;             // stream_count[max_bounces+1] ++ shadow_count[max_bounces]
+	DeviceBuffer counters;           // DevCounters
+	uint32_t capacity = 0;           // rays per stream plane
+	uint32_t arena_bounces = 0;
+	StreamBuf stream_buf[2]{};
+	ShadowBuf shadow_buf{};
+	float* hit_tfar = nullptr;
+	int32_t* hit_prim = nullptr;
+
+	// profiling
+	std::vector<TimedLaunch> pending;
+	std::vector<hipEvent_t> free_events;
+	mirt_kernel_times times{};
+};
+
+namespace {
+
+int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+	if (ctx) ctx->error = buf; else g_create_error = buf;
+	return code;
+}
+#define HIP_TRY(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
+
+uint32_t batch_limit(const mirt_ctx* c) {
+	uint32_t b = c->policy.buckets;
+	if (c->policy.max_batch && c->policy.max_batch < b) b = c->policy.max_batch;
+	return b ? b : 1;
+}
+
+uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
+	uint64_t blocks = (work_items + kBlock - 1) / kBlock;
+	const uint64_t cap = static_cast<uint64_t>(c->n_cu) * 8u;      // grid-stride beyond 8 workgroups per CU
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return static_cast<uint32_t>(blocks);
+}
+
+// Trace kernels are launched as a resident grid (as many 512-thread workgroups as their LDS footprint lets a
+// CU hold) and grid-stride over the stream, so each workgroup stages the BVH into LDS once per launch.
+constexpr uint32_t kLdsPerCu = 160u * 1024u;
+constexpr uint32_t kLdsStageBudget = 80u * 1024u;      // two workgroups (16 waves) per CU
+uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? std::max<uint32_t>(c->trace_lds_bytes, 16u) : kBruteChunk * 16u; }
+uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
+	uint32_t per_cu = kLdsPerCu / trace_lds(c);
+	if (per_cu > 4) per_cu = 4;                                       // 4 x 512 threads = 32 waves, the CU's limit
+	if (per_cu < 1) per_cu = 1;
+	uint64_t blocks = (work_items + kTraceBlock - 1) / kTraceBlock;
+	const uint64_t cap = static_cast<uint64_t>(c->n_cu) * per_cu;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	return static_cast<uint32_t>(blocks);
+}
+
+// Carve the frame-wide ray streams out of one allocation.
+int ensure_streams(mirt_ctx* c) {
+	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
+	const uint64_t cap64 = n_pix * batch_limit(c);
+	if (cap64 == 0) return MIRT_OK;
+	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
+	if (cap64 >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);
+	const uint32_t cap = static_cast<uint32_t>(cap64);
+	const uint32_t nb = c->policy.max_bounces;
+	if (cap == c->capacity && nb == c->arena_bounces && c->arena.ptr) return MIRT_OK;
+	const size_t planes = 2 * 14 + 2 + 17;
+	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
+	HIP_TRY(c, c->arena.ensure(planes * plane_bytes));
+	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 2 + 2) * sizeof(uint32_t)));
+	char* p = c->arena.as<char>();
+	auto take = [&]() { void* r = p; p += plane_bytes; return r; };
+	for (int b = 0; b < 2; b++) {
+		StreamBuf& s = c->stream_buf[b];
+		s.px = (float*)take(); s.py = (float*)take(); s.pz = (float*)take();
+		s.dx = (float*)take(); s.dy = (float*)take(); s.dz = (float*)take();
+		s.tr = (float*)take(); s.tg = (float*)take(); s.tb = (float*)take();
+		s.rr = (float*)take(); s.rg = (float*)take(); s.rb = (float*)take();
+		s.pdf = (float*)take(); s.path = (uint32_t*)take();
+	}
+	c->hit_tfar = (float*)take(); c->hit_prim = (int32_t*)take();
+	ShadowBuf& h = c->shadow_buf;
+	h.px = (float*)take(); h.py = (float*)take(); h.pz = (float*)take();
+	h.dx = (float*)take(); h.dy = (float*)take(); h.dz = (float*)take(); h.tfar = (float*)take();
+	h.sr = (float*)take(); h.sg = (float*)take(); h.sb = (float*)take();
+	h.rr = (float*)take(); h.rg = (float*)take(); h.rb = (float*)take();
+	h.er = (float*)take(); h.eg = (float*)take(); h.eb = (float*)take();
+	h.dest = (uint32_t*)take();
+	c->capacity = cap;
+	c->arena_bounces = nb;
+	return MIRT_OK;
+}
+
+int alloc_accumulator(mirt_ctx* c) {
+	const size_t floats = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize;
+	HIP_TRY(c, c->accumulator.ensure(floats * sizeof(float)));
+	if (floats) HIP_TRY(c, hipMemsetAsync(c->accumulator.ptr, 0, floats * sizeof(float), c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->counters.ptr, 0, sizeof(DevCounters), c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->accumulations = 0;
+	return MIRT_OK;
+}
+
+// ---- launch bracketing (policy.profile) ---------------------------------------------------------
+hipEvent_t take_event(mirt_ctx* c) {
+	if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	(void)hipEventCreate(&e);
+	return e;
+}
+void harvest(mirt_ctx* c) {
+	if (c->pending.empty()) return;
+	(void)hipStreamSynchronize(c->stream);
+	for (TimedLaunch& t : c->pending) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) { c->times.ms[t.klass] += ms; c->times.launches[t.klass]++; }
+		c->free_events.push_back(t.start); c->free_events.push_back(t.stop);
+	}
+	c->pending.clear();
+}
+struct Bracket {
+	mirt_ctx* c; int klass; hipEvent_t a = nullptr, b = nullptr;
+	Bracket(mirt_ctx* ctx, int k) : c(ctx), klass(k) {
+		if (c->policy.profile) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, c->stream); }
+	}
+	~Bracket() {
+		if (c->policy.profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back(TimedLaunch{ klass, a, b }); }
+	}
+};
+
+FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n) {
+	FrameParams fp{};
+	fp.cam = c->camera;
+	fp.h_tiles = c->h_tiles;
+	fp.first_tile = c->first_tile;
+	fp.n_pix = c->n_tiles * kTileSize;
+	fp.acc_base = acc_base;
+	fp.batch_n = batch_n;
+	fp.max_bounces = c->policy.max_bounces;
+	fp.buckets = c->policy.buckets;
+	fp.n_lights = c->scene.n_lights;
+	fp.mis = (c->policy.mis && c->scene.n_lights > 0) ? 1u : 0u;       // Q12 guard
+	return fp;
+}
+
+// One batch = up to `buckets` consecutive Accumulate() calls in flight together; consecutive
+// accumulation indices land in distinct buckets (Renderer.hpp:82), so no two paths of a batch
+// touch the same accumulator word.
+int launch_batch(mirt_ctx* c, uint32_t batch_n) {
+	const FrameParams fp = frame_params(c, c->accumulations, batch_n);
+	const uint32_t nb = c->policy.max_bounces;
+	const uint64_t total = static_cast<uint64_t>(fp.n_pix) * batch_n;
+	if (total == 0) return MIRT_OK;
+	uint32_t* stream_count = c->counts.as<uint32_t>();
+	uint32_t* shadow_count = stream_count + nb + 1;
+	DevCounters* ctr = c->counters.as<DevCounters>();
+	float* accum = c->accumulator.as<float>();
+	SceneDev sc = c->scene;
+	sc.use_bvh = c->policy.use_bvh;
+	const bool count = c->policy.count_traffic != 0;
+	const uint32_t grid = grid_for(c, total);
+	const uint32_t tgrid = trace_grid(c, total);
+	const uint32_t tlds = trace_lds(c);
+
+	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 2 + 2) * sizeof(uint32_t), c->stream));
+	{ Bracket t(c, MIRT_K_RAYGEN);
+	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], stream_count); }
+	for (uint32_t bounce = 0; bounce < nb; bounce++) {
+		const StreamBuf& in = c->stream_buf[bounce & 1u];
+		const StreamBuf& out = c->stream_buf[(bounce & 1u) ^ 1u];
+		{ Bracket t(c, MIRT_K_TRACE);
+		  if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr);
+		  else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr); }
+		{ Bracket t(c, MIRT_K_SHADE);
+		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
+		  else             hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
+		if (fp.mis && bounce + 1 < nb) {
+			Bracket t(c, MIRT_K_SHADOW);
+			if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, fp, c->shadow_buf, out, bounce, shadow_count, accum, ctr);
+			else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, fp, c->shadow_buf, out, bounce, shadow_count, accum, ctr);
+		}
+	}
+	HIP_TRY(c, hipGetLastError());
+	c->accumulations += batch_n;
+	if (c->policy.profile && c->pending.size() > 512) harvest(c);
+	return MIRT_OK;
+}
+
+template <class T>
+int upload(mirt_ctx* c, DeviceBuffer& buf, const std::vector<T>& host) {
+	HIP_TRY(c, buf.ensure(std::max<size_t>(host.size(), 1) * sizeof(T)));
+	if (!host.empty()) HIP_TRY(c, hipMemcpyAsync(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+	return MIRT_OK;
+}
+
+int check_ready(mirt_ctx* c) {
+	if (!c) return MIRT_ERR_ARG;
+	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
+	if (!c->have_camera) return fail(c, MIRT_ERR_STATE, "mirt_set_camera has not been called");
+	if (c->n_tiles == 0 || c->width == 0) return fail(c, MIRT_ERR_STATE, "mirt_resize has not been called (or no tiles owned)");
+	return MIRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* mirt_last_error(const mirt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int mirt_create(int device, mirt_ctx** out) {
+	if (!out) return fail(nullptr, MIRT_ERR_ARG, "out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) return fail(nullptr, MIRT_ERR_NO_DEVICE, "no HIP device available (%s); mirt has no CPU path", hipGetErrorString(e));
+	if (device < 0 || device >= n) return fail(nullptr, MIRT_ERR_ARG, "device %d out of range (have %d)", device, n);
+	e = hipSetDevice(device);
+	if (e != hipSuccess) return fail(nullptr, MIRT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+	mirt_ctx* c = new mirt_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = c->counters.ensure(sizeof(DevCounters));
+	if (e == hipSuccess) e = hipMemsetAsync(c->counters.ptr, 0, sizeof(DevCounters), c->stream);
+	if (e != hipSuccess) { int r = fail(nullptr, MIRT_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete c; return r; }
+	*out = c;
+	return MIRT_OK;
+}
+
+int mirt_destroy(mirt_ctx* c) {
+	if (!c) return MIRT_ERR_ARG;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	harvest(c);
+	for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->geom, &c->geom_mat, &c->mat_albedo, &c->mat_emission, &c->lights,
+	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->arena, &c->counts, &c->counters };
+	for (DeviceBuffer* b : bufs) b->release();
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return MIRT_OK;
+}
+
+int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* bvh_prims, uint32_t n_spheres,
+                   const mirt_bvh_node* nodes, uint32_t n_nodes, const mirt_material* materials, uint32_t n_materials,
+                   const int32_t* lights, uint32_t n_lights, const float ambient_color[3],
+                   const float* hdri_rgba, uint32_t hdri_w, uint32_t hdri_h) {
+	if (!c) return MIRT_ERR_ARG;
+	if (n_spheres && (!geometry || !bvh_prims)) return fail(c, MIRT_ERR_ARG, "geometry / bvh_prims is NULL");
+	if (n_nodes && !nodes) return fail(c, MIRT_ERR_ARG, "nodes is NULL");
+	if (!materials || n_materials == 0 || n_materials > MIRT_MAX_MATERIALS) return fail(c, MIRT_ERR_ARG, "need 1..%u materials, got %u", MIRT_MAX_MATERIALS, n_materials);
+	if (n_lights && !lights) return fail(c, MIRT_ERR_ARG, "lights is NULL");
+	if (!ambient_color || !hdri_rgba || hdri_w == 0 || hdri_h == 0) return fail(c, MIRT_ERR_ARG, "sky needs ambient_color and an hdri of at least 1x1");
+	// Validate everything the kernels index with: an out-of-range id would fault the GPU.
+	for (uint32_t i = 0; i < n_spheres; i++) {
+		if (geometry[i].material_ID < 0 || static_cast<uint32_t>(geometry[i].material_ID) >= n_materials ||
+		    bvh_prims[i].material_ID < 0 || static_cast<uint32_t>(bvh_prims[i].material_ID) >= n_materials)
+			return fail(c, MIRT_ERR_ARG, "sphere %u: material_ID out of range", i);
+	}
+	for (uint32_t i = 0; i < n_lights; i++)
+		if (lights[i] < 0 || static_cast<uint32_t>(lights[i]) >= n_spheres) return fail(c, MIRT_ERR_ARG, "light %u: index out of range", i);
+	for (uint32_t i = 0; i < n_nodes; i++) {
+		const mirt_bvh_node& nd = nodes[i];
+		if (nd.prim_count == 0) {
+			if (nd.first_id <= i || static_cast<uint64_t>(nd.first_id) + 1 >= n_nodes) return fail(c, MIRT_ERR_ARG, "node %u: child index %u invalid", i, nd.first_id);
+		} else if (static_cast<uint64_t>(nd.first_id) + nd.prim_count > n_spheres) return fail(c, MIRT_ERR_ARG, "node %u: prim range out of bounds", i);
+	}
+	if (n_spheres && n_nodes == 0) return fail(c, MIRT_ERR_ARG, "spheres without BVH nodes");
+	HIP_TRY(c, hipSetDevice(c->device));
+
+	std::vector<float4> sph(n_spheres), geo(n_spheres), alb(n_materials), emi(n_materials), sky(static_cast<size_t>(hdri_w) * hdri_h);
+	std::vector<int32_t> pm(n_spheres), gm(n_spheres), li(lights, lights + n_lights);
+	for (uint32_t i = 0; i < n_spheres; i++) {
+		sph[i] = make_float4(bvh_prims[i].position[0], bvh_prims[i].position[1], bvh_prims[i].position[2], bvh_prims[i].radius_sq);
+		geo[i] = make_float4(geometry[i].position[0], geometry[i].position[1], geometry[i].position[2], geometry[i].radius_sq);
+		pm[i] = bvh_prims[i].material_ID; gm[i] = geometry[i].material_ID;
+	}
+	for (uint32_t i = 0; i < n_materials; i++) {
+		alb[i] = make_float4(materials[i].albedo[0], materials[i].albedo[1], materials[i].albedo[2], 0.0f);
+		emi[i] = make_float4(materials[i].emission[0], materials[i].emission[1], materials[i].emission[2], 0.0f);
+	}
+	std::memcpy(sky.data(), hdri_rgba, sky.size() * sizeof(float4));
+	std::vector<float> recs;
+	uint32_t depth = 0;
+	{ const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
+	  if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str()); }
+	const uint32_t n_recs = static_cast<uint32_t>(recs.size() / 16);
+
+	int r;
+	if ((r = upload(c, c->recs, recs)) || (r = upload(c, c->spheres, sph)) || (r = upload(c, c->prim_mat, pm)) ||
+	    (r = upload(c, c->geom, geo)) || (r = upload(c, c->geom_mat, gm)) || (r = upload(c, c->mat_albedo, alb)) ||
+	    (r = upload(c, c->mat_emission, emi)) || (r = upload(c, c->lights, li)) || (r = upload(c, c->hdri, sky))) return r;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+	SceneDev& s = c->scene;
+	s.recs = c->recs.as<float4>(); s.spheres = c->spheres.as<float4>(); s.prim_mat = c->prim_mat.as<int32_t>();
+	s.geom = c->geom.as<float4>(); s.geom_mat = c->geom_mat.as<int32_t>();
+	s.mat_albedo = c->mat_albedo.as<float4>(); s.mat_emission = c->mat_emission.as<float4>();
+	s.lights = c->lights.as<int32_t>(); s.hdri = c->hdri.as<float4>();
+	s.n_spheres = n_spheres; s.n_recs = n_recs; s.n_mat = n_materials; s.n_lights = n_lights;
+	c->bvh_depth = depth;
+	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
+	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
+	if (static_cast<uint64_t>(n_recs) * 64u + static_cast<uint64_t>(n_spheres) * 16u <= kLdsStageBudget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
+	else { s.lds_recs = std::min<uint32_t>(n_recs, (kLdsStageBudget - 16u * 1024u) / 64u); s.lds_spheres = 0; }
+	c->trace_lds_bytes = s.lds_recs * 64u + s.lds_spheres * 16u;
+	{
+		const int lds_max = static_cast<int>(kLdsPerCu);
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_closest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_closest<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shadow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_shadow), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+	}
+	for (int k = 0; k < 3; k++) s.ambient[k] = ambient_color[k];
+	s.hdri_w = static_cast<int32_t>(hdri_w); s.hdri_h = static_cast<int32_t>(hdri_h);
+	s.hdri_fw = static_cast<float>(static_cast<int32_t>(hdri_w) - 1);                 // Application.cpp:230-231
+	s.hdri_fh = static_cast<float>(static_cast<int32_t>(hdri_h) - 1);
+	{ const float a = ambient_color[0], b = ambient_color[1], d = ambient_color[2];
+	  const float m1 = (b < d) ? d : b; const float m0 = (a < m1) ? m1 : a; s.has_ambient = (m0 > 0.0f) ? 1u : 0u; }   // Renderer.hpp:79
+	c->have_scene = true;
+	return MIRT_OK;
+}
+
+int mirt_set_camera(mirt_ctx* c, const float pos[3], const float orient_xyzw[4], float half_width, float half_height, float z, float exposure) {
+	if (!c) return MIRT_ERR_ARG;
+	if (!pos || !orient_xyzw) return fail(c, MIRT_ERR_ARG, "pos / orient is NULL");
+	for (int k = 0; k < 3; k++) c->camera.pos[k] = pos[k];
+	for (int k = 0; k < 4; k++) c->camera.orient[k] = orient_xyzw[k];
+	c->camera.half_width = half_width; c->camera.half_height = half_height; c->camera.z = z; c->camera.exposure = exposure;
+	c->have_camera = true;
+	return MIRT_OK;
+}
+
+int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
+	if (!c || !p) return MIRT_ERR_ARG;
+	if (p->max_bounces < 1 || p->max_bounces > 1024) return fail(c, MIRT_ERR_ARG, "max_bounces %u out of range", p->max_bounces);
+	if (p->buckets < 1 || p->buckets > MIRT_MAX_BUCKETS) return fail(c, MIRT_ERR_ARG, "buckets %u out of range 1..%u", p->buckets, MIRT_MAX_BUCKETS);
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	const bool realloc_acc = p->buckets != c->policy.buckets;
+	c->policy = *p;
+	if (realloc_acc && c->n_tiles) { int r = alloc_accumulator(c); if (r) return r; }
+	return MIRT_OK;
+}
+int mirt_get_policy(const mirt_ctx* c, mirt_policy* p) { if (!c || !p) return MIRT_ERR_ARG; *p = c->policy; return MIRT_OK; }
+
+int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
+	if (!c) return MIRT_ERR_ARG;
+	if (width > 65536 || height > 65536) return fail(c, MIRT_ERR_ARG, "size %ux%u too large", width, height);
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->width = width; c->height = height;
+	c->h_tiles = width / MIRT_TILE_ROOT; c->v_tiles = height / MIRT_TILE_ROOT;          // Renderer.hpp:59-60
+	c->first_tile = 0; c->n_tiles = c->h_tiles * c->v_tiles;
+	HIP_TRY(c, c->framebuffer.ensure(std::max<size_t>(static_cast<size_t>(width) * height, 1) * sizeof(float4)));
+	HIP_TRY(c, hipMemsetAsync(c->framebuffer.ptr, 0, c->framebuffer.bytes, c->stream));
+	return alloc_accumulator(c);                                                      // Renderer.hpp:61-62
+}
+
+int mirt_set_tile_range(mirt_ctx* c, uint32_t first_tile, uint32_t n_tiles) {
+	if (!c) return MIRT_ERR_ARG;
+	const uint64_t all = static_cast<uint64_t>(c->h_tiles) * c->v_tiles;
+	if (static_cast<uint64_t>(first_tile) + n_tiles > all) return fail(c, MIRT_ERR_ARG, "tile range [%u,+%u) exceeds %llu tiles", first_tile, n_tiles, (unsigned long long)all);
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->first_tile = first_tile; c->n_tiles = n_tiles;
+	return alloc_accumulator(c);
+}
+
+int mirt_reset(mirt_ctx* c) {
+	if (!c) return MIRT_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	return alloc_accumulator(c);                                                      // Renderer.hpp:64-67
+}
+
+int mirt_accumulate_async(mirt_ctx* c, uint32_t n_calls) {
+	int r = check_ready(c); if (r) return r;
+	HIP_TRY(c, hipSetDevice(c->device));
+	if ((r = ensure_streams(c))) return r;
+	const uint32_t limit = batch_limit(c);
+	while (n_calls) {
+		const uint32_t bn = std::min(n_calls, limit);
+		if ((r = launch_batch(c, bn))) return r;
+		n_calls -= bn;
+	}
+	return MIRT_OK;
+}
+int mirt_synchronize(mirt_ctx* c) {
+	if (!c) return MIRT_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return MIRT_OK;
+}
+int mirt_accumulate(mirt_ctx* c, uint32_t n_calls) {
+	int r = mirt_accumulate_async(c, n_calls);
+	if (r) return r;
+	return mirt_synchronize(c);
+}
+int mirt_get_accumulations(const mirt_ctx* c, uint32_t* a) { if (!c || !a) return MIRT_ERR_ARG; *a = c->accumulations; return MIRT_OK; }
+
+int mirt_accumulator_floats(const mirt_ctx* c, size_t* n) {
+	if (!c || !n) return MIRT_ERR_ARG;
+	*n = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize;
+	return MIRT_OK;
+}
+int mirt_read_accumulator(mirt_ctx* c, float* dst) {
+	if (!c || !dst) return MIRT_ERR_ARG;
+	size_t n = 0; mirt_accumulator_floats(c, &n);
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (n) HIP_TRY(c, hipMemcpy(dst, c->accumulator.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+	return MIRT_OK;
+}
+int mirt_accumulator_device(mirt_ctx* c, void** ptr, size_t* bytes) {
+	if (!c || !ptr || !bytes) return MIRT_ERR_ARG;
+	size_t n = 0; mirt_accumulator_floats(c, &n);
+	*ptr = c->accumulator.ptr; *bytes = n * sizeof(float);
+	return MIRT_OK;
+}
+int mirt_load_accumulator(mirt_ctx* c, const float* src, int src_is_device, uint32_t accumulations) {
+	if (!c || !src) return MIRT_ERR_ARG;
+	size_t n = 0; mirt_accumulator_floats(c, &n);
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (n) HIP_TRY(c, hipMemcpy(c->accumulator.ptr, src, n * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	c->accumulations = accumulations;
+	return MIRT_OK;
+}
+
+int mirt_render(mirt_ctx* c, float* rgba_host) {
+	int r = check_ready(c); if (r) return r;
+	if (!rgba_host) return fail(c, MIRT_ERR_ARG, "rgba_host is NULL");
+	const uint32_t k = c->policy.buckets;
+	if (c->accumulations == 0 || (c->accumulations % k) != 0) return MIRT_NOT_READY;               // Renderer.hpp:437
+	HIP_TRY(c, hipSetDevice(c->device));
+	const float scale = c->camera.exposure / static_cast<float>(c->accumulations / k);              // Renderer.hpp:439
+	const uint32_t n_pix = c->n_tiles * kTileSize;
+	{ Bracket t(c, MIRT_K_RESOLVE);
+	  hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n_pix)), dim3(kBlock), 0, c->stream, c->accumulator.as<float>(), c->framebuffer.as<float4>(),
+	                     n_pix, c->first_tile, c->h_tiles, c->width, k, scale); }
+	HIP_TRY(c, hipGetLastError());
+	std::vector<float> staging(static_cast<size_t>(c->width) * c->height * 4);
+	HIP_TRY(c, hipMemcpyAsync(staging.data(), c->framebuffer.ptr, staging.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (uint32_t t = c->first_tile; t < c->first_tile + c->n_tiles; t++) {                         // only this context's tiles
+		const uint32_t x0 = MIRT_TILE_ROOT * (t % c->h_tiles), y0 = MIRT_TILE_ROOT * (t / c->h_tiles);
+		for (uint32_t row = 0; row < MIRT_TILE_ROOT; row++) {
+			const size_t off = (static_cast<size_t>(y0 + row) * c->width + x0) * 4;
+			std::memcpy(rgba_host + off, staging.data() + off, MIRT_TILE_ROOT * 4 * sizeof(float));
+		}
+	}
+	return MIRT_OK;
+}
+
+int mirt_get_counters(mirt_ctx* c, mirt_counters* out) {
+	if (!c || !out) return MIRT_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	DevCounters d;
+	HIP_TRY(c, hipMemcpy(&d, c->counters.ptr, sizeof d, hipMemcpyDeviceToHost));
+	out->rays = d.rays; out->shadow_rays = d.shadow_rays; out->nodes = d.nodes; out->spheres = d.spheres;
+	out->shadow_nodes = d.shadow_nodes; out->shadow_spheres = d.shadow_spheres; out->terminated = d.terminated; out->dropped = d.dropped;
+	return MIRT_OK;
+}
+int mirt_get_kernel_times(mirt_ctx* c, mirt_kernel_times* out, int reset) {
+	if (!c || !out) return MIRT_ERR_ARG;
+	HIP_TRY(c, hipSetDevice(c->device));
+	harvest(c);
+	*out = c->times;
+	if (reset) c->times = mirt_kernel_times{};
+	return MIRT_OK;
+}
+int mirt_get_stream(mirt_ctx* c, void** s) { if (!c || !s) return MIRT_ERR_ARG; *s = c->stream; return MIRT_OK; }
+
+// ---- stage-level entry points -------------------------------------------------------------------
+int mirt_debug_raygen(mirt_ctx* c, uint32_t accumulations, float* p_xyz, float* dir_xyz) {
+	int r = check_ready(c); if (r) return r;
+	if (!p_xyz || !dir_xyz || accumulations == 0) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	HIP_TRY(c, hipSetDevice(c->device));
+	if ((r = ensure_streams(c))) return r;
+	const FrameParams fp = frame_params(c, accumulations - 1, 1);
+	const size_t n = fp.n_pix;
+	hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], c->counts.as<uint32_t>());
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	const StreamBuf& s = c->stream_buf[0];
+	float* srcs[6] = { s.px, s.py, s.pz, s.dx, s.dy, s.dz };
+	for (int k = 0; k < 3; k++) {
+		HIP_TRY(c, hipMemcpy(p_xyz + k * n, srcs[k], n * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(c, hipMemcpy(dir_xyz + k * n, srcs[3 + k], n * 4, hipMemcpyDeviceToHost));
+	}
+	return MIRT_OK;
+}
+
+int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const float* dir_xyz, float* tfar_out, int32_t* prim_out) {
+	if (!c) return MIRT_ERR_ARG;
+	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
+	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	HIP_TRY(c, hipSetDevice(c->device));
+	DeviceBuffer rays, res, cnt;
+	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(4));
+	float* d = rays.as<float>();
+	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
+	const uint32_t n32 = static_cast<uint32_t>(n);
+	HIP_TRY(c, hipMemcpy(cnt.ptr, &n32, 4, hipMemcpyHostToDevice));
+	StreamBuf in{};
+	in.px = d; in.py = d + n; in.pz = d + 2 * n; in.dx = d + 3 * n; in.dy = d + 4 * n; in.dz = d + 5 * n;
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
+	DevCounters* scratch_ctr = nullptr;
+	DeviceBuffer ctr; HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
+	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
+	hipLaunchKernelGGL(k_trace_closest<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), scratch_ctr);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(prim_out, res.as<float>() + n, n * 4, hipMemcpyDeviceToHost);
+	rays.release(); res.release(); cnt.release(); ctr.release();
+	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_closest: %s", hipGetErrorString(e));
+	return MIRT_OK;
+}
+
+int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const float* dir_xyz, const float* tfar, uint8_t* occluded_out) {
+	if (!c) return MIRT_ERR_ARG;
+	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
+	if (!p_xyz || !dir_xyz || !tfar || !occluded_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	HIP_TRY(c, hipSetDevice(c->device));
+	DeviceBuffer rays, occ;
+	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n));
+	float* d = rays.as<float>();
+	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemcpy(d + 6 * n, tfar, n * 4, hipMemcpyHostToDevice));
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
+	hipLaunchKernelGGL(k_debug_shadow, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, d, d + 3 * n, d + 6 * n, occ.as<uint8_t>(), static_cast<uint32_t>(n));
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(occluded_out, occ.ptr, n, hipMemcpyDeviceToHost);
+	rays.release(); occ.release();
+	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_shadow: %s", hipGetErrorString(e));
+	return MIRT_OK;
+}
+
+int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) {
+	if (!c) return MIRT_ERR_ARG;
+	static const int n_in[8] = { 1, 2, 1, 2, 2, 6, 8, 3 }, n_out[8] = { 2, 1, 1, 3, 3, 10, 5, 5 };
+	if (fn < 0 || fn > 7 || !in || !out || n == 0 || n >= (1u << 28)) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	HIP_TRY(c, hipSetDevice(c->device));
+	DeviceBuffer din, dout;
+	HIP_TRY(c, din.ensure(n * n_in[fn] * 4)); HIP_TRY(c, dout.ensure(n * n_out[fn] * 4));
+	HIP_TRY(c, hipMemcpy(din.ptr, in, n * n_in[fn] * 4, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_debug_math, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, fn, static_cast<uint32_t>(n), din.as<float>(), dout.as<float>());
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(out, dout.ptr, n * n_out[fn] * 4, hipMemcpyDeviceToHost);
+	din.release(); dout.release();
+	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_math: %s", hipGetErrorString(e));
+	return MIRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,35 @@
+"""Multi-GPU host logic: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm).
+
+The path shards by independent units: tiles are independent (Renderer.hpp:75-88) and every random draw depends only
+on the global LaunchIndex, ID and accumulations (Renderer.hpp:107,117), so rank r renders the contiguous LaunchIndex
+range tile_range(T, r, N) with the scene replicated, and the only exchange is ONE gather of the accumulator slabs
+([tile][bucket][rgb][256] f32, Renderer.hpp:43-46) to rank 0 at the end.  No all-reduce, no per-frame traffic.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def tile_range(n_tiles: int, rank: int, world: int):
+    """Contiguous, balanced split of [0, n_tiles): the first n_tiles % world ranks own one extra tile."""
+    base, extra = divmod(n_tiles, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def gather_accumulator(local: torch.Tensor, n_tiles: int, rank: int, world: int, buckets: int):
+    """Gather per-rank slabs [count_r, buckets, 3, 256] to rank 0 -> [n_tiles, buckets, 3, 256] (None elsewhere)."""
+    if world == 1:
+        return local
+    counts = [tile_range(n_tiles, r, world)[1] for r in range(world)]
+    pad_to = max(counts)
+    send = local
+    if local.shape[0] != pad_to:                      # dist.gather wants equal shapes: pad the short slabs by one tile
+        send = torch.zeros((pad_to,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, gather_list=bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

@@ -1,0 +1,30 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_mirt():
+    """The package directory name has hyphens, so it is imported through importlib."""
+    return importlib.import_module("cpu-raytracing-experiments_amd")
+
+
+@pytest.fixture(scope="session")
+def mirt():
+    return load_mirt()
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle_binding
+    return oracle_binding.load()

@@ -1,0 +1,240 @@
+"""CPU tests (-m "not gpu"): the oracle against the reference's known answers and the committed golden vectors,
+the three traversal modes against each other, the host-side BVH builder / light list, scene authoring, and the
+C-ABI library's exports."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import ROOT, load_mirt
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---- Random.hpp known answers (re-derived from the formulas, not from reference tests) ----
+def test_rng_kat(oracle_lib):
+    lib = oracle_lib
+    assert lib.orc_hash_u32(0) == 0xE6FE3BEB and lib.orc_hash_u32(1) == 0xE02DC198
+    kat = {
+        (1, 0): (0xEF386249, [0x244781FE, 0xF6C171EC, 0x519DB614]),
+        (1, 33): (0x56410662, [0x3989A65F, 0xCA475290, 0x6C1A075D]),
+        (1, 8415): (0x733AA5F5, [0x8D032E4D, 0x5E636987, 0x789D5B7E]),
+        (2, 0): (0xF32E75BE, [0x87C870BC, 0xBDC3E819, 0x3F6B7189]),
+        (5, 8455): (0xD9B98C80, [0x77AE2422, 0x286451C6, 0x1F3C4EA1]),
+        (1, 553648095): (0xA71BCD85, [0xA3B1A1D4, 0x420F7B06, 0x251CD6B0]),
+    }
+    for (x, y), (h, outs) in kat.items():
+        assert lib.orc_hash_2d(x, y) == h
+        s = C.c_uint32(h)
+        assert [lib.orc_pcg_generate(C.byref(s)) for _ in range(3)] == outs
+    assert lib.orc_make_unit_float(0x244781FE) == np.float32(0.1417161226272583)
+    assert lib.orc_make_unit_float(0xF6C171EC) == np.float32(0.9638892412185669)
+    assert lib.orc_make_unit_float(0xFFFFFF7F) == np.float32(0.99999994)
+    assert lib.orc_make_unit_float(0xFFFFFF80) == 1.0 and lib.orc_make_unit_float(0xFFFFFFFF) == 1.0   # Q13
+    s = C.c_uint32(123)
+    assert lib.orc_rand_bounded_int(C.byref(s), 1) == 0
+
+
+def test_scene_rng_matches_oracle(mirt, oracle_lib):
+    """scene.py's Python PCG (synthetic-scene generator) is the same generator as the oracle's."""
+    st = mirt.scene.hash_u32(1)
+    assert st == oracle_lib.orc_hash_u32(1)
+    got = mirt.scene.pcg_floats(st, 64)
+    s = C.c_uint32(st)
+    want = np.array([oracle_lib.orc_make_unit_float(oracle_lib.orc_pcg_generate(C.byref(s))) for _ in range(64)], dtype=np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_fast_math_properties(oracle_lib):
+    d = np.load(os.path.join(GOLDEN, "math_vectors.npz"))
+    s, c = C.c_float(), C.c_float()
+    for i in range(0, len(d["sincos_x"]), 7):
+        oracle_lib.orc_fast_sincos(float(d["sincos_x"][i]), C.byref(s), C.byref(c))
+        assert np.float32(s.value).view(np.uint32) == d["sincos_s"][i].view(np.uint32)
+        assert np.float32(c.value).view(np.uint32) == d["sincos_c"][i].view(np.uint32)
+    x = d["sincos_x"].astype(np.float64)
+    assert np.abs(d["sincos_s"] - np.sin(x)).max() < 2e-6 and np.abs(d["sincos_c"] - np.cos(x)).max() < 2e-6
+    assert np.abs(d["atan2"] - np.arctan2(d["atan2_y"].astype(np.float64), d["atan2_x"])).max() < 2e-3
+    ok = np.abs(d["asin_x"]) <= 1
+    assert np.abs(d["asin"][ok] - np.arcsin(d["asin_x"][ok].astype(np.float64))).max() < 1e-3
+    assert oracle_lib.orc_median5(5, 1, 4, 2, 3) == 3.0 and oracle_lib.orc_median5(1, 1, 9, 9, 2) == 2.0
+
+
+# ---- analytic known answer: white furnace (Application.cpp:218-223) ---------------------------------------
+@pytest.mark.parametrize("mode", [ob.TRAV_BRUTE, ob.TRAV_STREAM_BVH, ob.TRAV_PER_RAY_BVH])
+def test_white_furnace_is_exactly_one(mirt, mode):
+    o = ob.Oracle(mirt.scene.white_furnace(), max_bounces=16, trav_mode=mode)
+    o.Resize(48, 32)
+    o.Accumulate(5)
+    acc = o.accumulator()
+    assert np.all(acc == 1.0)                     # one sample of radiance exactly 1.0 in every bucket
+    img = o.Render()
+    r = np.float32(1.0)
+    assert img is not None and np.all(img[..., 3] == 1.0)
+    assert np.ptp(img[..., :3].reshape(-1, 3), axis=0).max() == 0.0      # constant image = tonemap(1,1,1)
+    assert o.counters()["terminated"] == 5 * 48 * 32
+
+
+# ---- golden vectors ----------------------------------------------------------------------------------------
+CASES = {
+    "default9_64x64_10spp_b16": dict(scene="default9", w=64, h=64, spp=10, mb=16),
+    "default9_64x64_5spp_nomis": dict(scene="default9", w=64, h=64, spp=5, mb=16, mis=False),
+    "furnace_32x32_5spp": dict(scene="furnace", w=32, h=32, spp=5, mb=16),
+    "S8_cfg1_64x64_1spp_b2": dict(scene="S8a", w=64, h=64, spp=1, mb=2),
+    "S1000_64x64_5spp_b5": dict(scene="S1000a", w=64, h=64, spp=5, mb=5),
+    "S1000_48x32_16buckets_16spp_b3": dict(scene="S1000", w=48, h=32, spp=16, mb=3, buckets=16),
+}
+
+
+def make_scene(mirt, name):
+    s = mirt.scene
+    return {"default9": s.default9, "furnace": s.white_furnace, "S8a": lambda: s.synthetic(8, ambient=0.5),
+            "S1000a": lambda: s.synthetic(1000, ambient=0.5), "S1000": lambda: s.synthetic(1000)}[name]()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("mode", [ob.TRAV_BRUTE, ob.TRAV_PER_RAY_BVH])
+def test_oracle_matches_golden(mirt, name, mode):
+    cfg = CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o = ob.Oracle(make_scene(mirt, cfg["scene"]), max_bounces=cfg["mb"], buckets=cfg.get("buckets", 5), mis=cfg.get("mis", True), trav_mode=mode)
+    o.Resize(cfg["w"], cfg["h"])
+    o.Accumulate(cfg["spp"])
+    assert np.array_equal(bits(o.accumulator()), bits(g["accumulator"]))
+    img = o.Render()
+    if g["frame"].size:
+        assert np.array_equal(bits(img), bits(g["frame"]))
+    else:
+        assert img is None                                # accumulations % buckets != 0 (Renderer.hpp:437)
+    c = o.counters()
+    assert c["rays"] == int(g["rays"]) and c["shadow_rays"] == int(g["shadow_rays"]) and c["terminated"] == int(g["terminated"])
+
+
+def test_accumulation_is_incremental_and_thread_independent(mirt):
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    a = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH, threads=1); a.Resize(64, 48); a.Accumulate(7)
+    b = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH, threads=8); b.Resize(64, 48)
+    for _ in range(7):
+        b.Accumulate(1)
+    assert np.array_equal(bits(a.accumulator()), bits(b.accumulator()))
+    # bucket b receives samples with accumulations % 5 == b (Q1): after 7 calls buckets 1,2 hold two samples
+    assert a.accumulations == 7
+    a.ResetAccumulator()
+    assert a.accumulations == 0 and not a.accumulator().any()
+
+
+def test_robust_bvh_equals_brute_force(mirt):
+    """Mode 2 (the HIP kernels' traversal) must return the as-shipped brute-force result bit for bit."""
+    for sc, w, h, spp, mb in [(mirt.scene.synthetic(1000, ambient=0.5), 256, 256, 5, 5), (mirt.scene.synthetic(4000), 128, 128, 5, 9),
+                              (mirt.scene.default9(), 128, 128, 5, 16)]:
+        ref = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); ref.Resize(w, h); ref.Accumulate(spp)
+        twin = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); twin.Resize(w, h); twin.Accumulate(spp)
+        assert np.array_equal(bits(ref.accumulator()), bits(twin.accumulator()))
+        cr, ct = ref.counters(), twin.counters()
+        assert cr["rays"] == ct["rays"] and cr["shadow_rays"] == ct["shadow_rays"] and cr["terminated"] == ct["terminated"]
+        assert ct["spheres"] < cr["spheres"]
+
+
+def test_reference_stream_bvh_differs_from_its_brute_force_only_rarely(mirt):
+    """Mode 1 (BVH.hpp:320-358 as written) is NOT equivalent to mode 0 (Q17 clamp + order dependence); quantify."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    ref = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); ref.Resize(256, 256); ref.Accumulate(5)
+    st = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_STREAM_BVH); st.Resize(256, 256); st.Accumulate(5)
+    differing = (bits(ref.accumulator()) != bits(st.accumulator())).reshape(-1, 5, 3, 256).any(axis=(1, 2)).sum()
+    assert differing <= 64                                  # a handful of pixels out of 65,536
+    d9 = mirt.scene.default9()
+    a = ob.Oracle(d9, trav_mode=ob.TRAV_BRUTE); a.Resize(128, 128); a.Accumulate(5)
+    b = ob.Oracle(d9, trav_mode=ob.TRAV_STREAM_BVH); b.Resize(128, 128); b.Accumulate(5)
+    assert np.array_equal(bits(a.accumulator()), bits(b.accumulator()))      # no large spheres -> no events
+
+
+# ---- host-side builder (product) vs oracle restatement of BVH.hpp:90-206 -------------------------------------
+@pytest.mark.parametrize("which", ["default9", "furnace", "S8", "S1000", "S6000"])
+def test_bvh_builder_matches_oracle(mirt, which):
+    s = mirt.scene
+    sc = {"default9": s.default9, "furnace": s.white_furnace, "S8": lambda: s.synthetic(8), "S1000": lambda: s.synthetic(1000), "S6000": lambda: s.synthetic(6000)}[which]()
+    o = ob.Oracle(sc, trav_mode=0)
+    nodes_o, prims_o = o.bvh()
+    nodes_p, prims_p = mirt.bvh_build(sc.geometry)
+    assert len(nodes_p) == 2 * len(sc.geometry) - 1
+    assert np.array_equal(nodes_o.view(np.uint8), nodes_p.view(np.uint8))
+    assert np.array_equal(prims_o.view(np.uint8), prims_p.view(np.uint8))
+    assert np.array_equal(o.lights(), mirt.light_list(sc.geometry, sc.material))
+    # structural invariants: leaves hold one prim, every prim once, children boxes inside the parent's
+    leaves = nodes_p[nodes_p["prim_count"] != 0]
+    assert np.all(leaves["prim_count"] == 1) and sorted(leaves["first_id"].tolist()) == list(range(len(sc.geometry)))
+    for i, n in enumerate(nodes_p):
+        if n["prim_count"] == 0:
+            for c in (n["first_id"], n["first_id"] + 1):
+                assert c > i and np.all(nodes_p[c]["min_bound"] >= n["min_bound"]) and np.all(nodes_p[c]["max_bound"] <= n["max_bound"])
+
+
+def test_bvh_golden(mirt):
+    g = np.load(os.path.join(GOLDEN, "S1000_bvh.npz"))
+    nodes, prims = mirt.bvh_build(mirt.scene.synthetic(1000).geometry)
+    assert np.array_equal(nodes.view(np.uint8).reshape(-1, 32), g["nodes"]) and np.array_equal(prims.view(np.uint8).reshape(-1, 32), g["prims"])
+    assert np.array_equal(mirt.light_list(mirt.scene.synthetic(1000).geometry, mirt.scene.synthetic(1000).material), g["lights"])
+
+
+def test_bvh_edge_cases(mirt):
+    nodes, prims = mirt.bvh_build(np.zeros(0, dtype=mirt.SPHERE))
+    assert len(nodes) == 0 and len(prims) == 0
+    one = mirt.scene.white_furnace().geometry
+    nodes, prims = mirt.bvh_build(one)
+    assert len(nodes) == 1 and nodes[0]["prim_count"] == 1 and nodes[0]["first_id"] == 0
+    dup = np.repeat(one, 5)                                    # identical centroids: ties broken by index
+    nodes, prims = mirt.bvh_build(dup)
+    assert len(nodes) == 9
+
+
+def test_scene_authoring(mirt):
+    s = mirt.scene
+    d9 = s.default9()
+    assert len(d9.geometry) == 9 and len(d9.material) == 9 and d9.geometry.dtype.itemsize == 32 and d9.material.dtype.itemsize == 96
+    cam = d9.camera
+    cam.resize(512, 512)
+    assert cam.half_width == 256 and cam.z == np.float32(256) * ((np.float32(-2) / np.float32(24)) * np.float32(40))
+    assert abs(np.linalg.norm(cam.orient) - 1) < 1e-6
+    # looking down -z with up +y is the identity orientation
+    assert np.allclose(s.Camera(direction=(0, 0, -1)).orient, [0, 0, 0, 1])
+    a, b = s.synthetic(1000), s.synthetic(1000)
+    assert a.geometry.tobytes() == b.geometry.tobytes() and a.material.tobytes() == b.material.tobytes()
+    assert (a.geometry["material_ID"] == 16).sum() == 1000 // 64 and a.geometry["material_ID"].max() == 16
+    assert s.synthetic(8).geometry["material_ID"][7] == 16
+    assert set(s.CONFIGS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"}
+
+
+# ---- the C-ABI library ----------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(mirt):
+    header = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(mirt_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 28
+    lib = mirt.load_library()
+    raw = C.CDLL(mirt.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in mirt.h but not exported"
+    assert declared == set(lib._declared)
+
+
+def test_struct_layouts_match_header(mirt):
+    assert C.sizeof(mirt.Policy) == 32 and C.sizeof(mirt.Counters) == 64 and C.sizeof(mirt.KernelTimes) == 80
+    assert mirt.SPHERE.fields["radius_sq"][1] == 12 and mirt.SPHERE.fields["material_ID"][1] == 16
+    assert mirt.MATERIAL.fields["emission"][1] == 36 and mirt.NODE.fields["first_id"][1] == 12 and mirt.NODE.fields["max_bound"][1] == 16
+
+
+def test_no_cpu_fallback(mirt):
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mirt.MirtError, match="no HIP device|mirt_create failed"):
+        mirt.Renderer(mirt.scene.default9())
+    lib = mirt.load_library()
+    assert lib.mirt_accumulate(None, 1) < 0 and lib.mirt_render(None, None) < 0
