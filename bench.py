@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s (primary+bounce) of the Renderer::Accumulate hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "cfg2"): synthetic scene S(1000) (ground + 999 random spheres, 17
+materials, 15 emissive spheres, ambient 0.5), SAH BVH, MIS on, Policy.max_bounces = 5 (primary + 4 bounces),
+1024x1024 pixels, 64 accumulations.  One STEP = one such 64-accumulation pass (64 x Renderer::Accumulate()).
+N > 1: weak scaling — the image grows to N x 1024^2 pixels and rank r renders the r-th contiguous range of 4096
+tiles (no data-path collective; one RCCL gather of the accumulator slabs after the timed region, timed separately).
+
+value = rays handed to closest-hit traversal by all ranks (Renderer.hpp:165: primary + extension rays; shadow rays
+are reported separately) / max-over-ranks wall time of the K timed steps, inputs resident in HBM.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(c):
+    """per closest-hit ray 24 B (p,dir) + 12 B (tfar,primID,matID) + 32 B per BVH node box-tested
+    + 32 B per sphere tested."""
+    return 36 * c["rays"] + 32 * (c["nodes"] + c["spheres"])
+
+
+def shape_for(n_gpus, base=1024):
+    w = h = base
+    k = n_gpus
+    while k > 1:                      # double width, then height, ...: 1024x1024, 2048x1024, 2048x2048, 4096x2048
+        if w <= h:
+            w *= 2
+        else:
+            h *= 2
+        k //= 2
+    assert (w // 16) * (h // 16) == n_gpus * (base // 16) ** 2, "n_gpus must be a power of two"
+    return w, h
+
+
+def cpu_baseline(mirt, scene_fn, cfg, log):
+    """The reference's own CPU path, as restated in oracle/ (the reference itself cannot be built here): stream-BVH
+    traversal (BVH.hpp:320-358) with the AVX2 8-ray sphere kernel, tiles over all host threads — on a bounded sample
+    (a few accumulations of the same 1024x1024 workload; rays/s does not depend on the accumulation count)."""
+    import oracle_binding as ob
+    # host threads this job may use: the GPU box gives a 1-GPU job a 16-CPU share, whatever the machine has
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    o = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_STREAM_BVH, threads=threads)
+    o.Resize(cfg["width"], cfg["height"])
+    t0 = time.perf_counter(); o.Accumulate(1); t1 = time.perf_counter() - t0
+    n = min(16, max(3, int(15.0 / max(t1, 1e-3))))
+    o.ResetAccumulator()
+    t0 = time.perf_counter(); o.Accumulate(n); dt = time.perf_counter() - t0
+    rays = o.counters()["rays"]
+    log(f"cpu baseline: {n} accumulations, {rays} rays in {dt:.2f}s on {threads} threads")
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+            "sample": f"{n} of {cfg['spp']} accumulations of the same {cfg['width']}x{cfg['height']} S(1000) workload, "
+                      f"oracle stream-BVH mode (reference BVH.hpp:320-358 restated; reference itself unbuildable here)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=None, help="accumulations per step (default: cfg2's 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counts", action="store_true", help="skip the counting replay (roofline.achieved becomes null)")
+    args = ap.parse_args()
+
+    import torch
+    mirt = importlib.import_module("cpu-raytracing-experiments_amd")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    cfg = dict(mirt.scene.CONFIGS["cfg2"])
+    if args.spp:
+        cfg["spp"] = args.spp
+    scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
+    width, height = shape_for(world, cfg["width"])
+    tiles = (width // 16) * (height // 16)
+    first, count = mirt.distributed.tile_range(tiles, rank, world)
+
+    r = mirt.Renderer(scene_fn(), device=local_rank, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True,
+                      use_bvh=bool(cfg["use_bvh"]), profile=True)
+    r.Resize(width, height)
+    if world > 1:
+        r.SetTileRange(first, count)
+    spp, K, W = cfg["spp"], args.steps, args.warmup
+
+    def sync_all():
+        r.Synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- timed pass: W warmup steps, then exactly K steps ----
+    for _ in range(W):
+        r.Accumulate(spp)
+    r.kernel_times(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        r.Accumulate(spp)              # synchronous: returns after the context's stream has drained
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ktimes = r.kernel_times(reset=True)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- one gather of the accumulated radiance to rank 0 (RCCL over xGMI), outside the timed region ----
+    gather_ms = None
+    if dist is not None:
+        local = mirt.distributed.device_tensor(*r.accumulator_device(), shape=(count, cfg["buckets"], 3, 256))
+        sync_all()
+        g0 = time.perf_counter()
+        full = mirt.distributed.gather_accumulator(local, tiles, rank, world, cfg["buckets"])
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert tuple(full.shape) == (tiles, cfg["buckets"], 3, 256)
+
+    # ---- counting replay of the same steps: rays / nodes / spheres of exactly the timed accumulation indices ----
+    counts = None
+    if not args.no_counts:
+        r.set_policy(count_traffic=1, profile=0)
+        r.ResetAccumulator()
+        for _ in range(W):
+            r.Accumulate(spp)
+        c0 = r.counters()
+        for _ in range(K):
+            r.Accumulate(spp)
+        c1 = r.counters()
+        counts = {k: c1[k] - c0[k] for k in c1}
+    else:
+        counts = None
+    rays_local = counts["rays"] if counts else None
+    if rays_local is None:                                  # rays are counted in every mode
+        c = r.counters(); rays_local = c["rays"] * K // (K + W)
+    rays_total = rays_local
+    if dist is not None:
+        t = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rays_total = int(t.item())
+
+    if rank == 0:
+        value = rays_total / elapsed / 1e6
+        roofline = None
+        tr = ktimes["trace"]
+        if tr["launches"]:
+            avg_ms = tr["ms"] / tr["launches"]
+            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "launches": tr["launches"], "avg_launch_ms": avg_ms}
+            if counts:
+                ab = algorithmic_bytes(counts)
+                ach = ab / (tr["ms"] * 1e-3) / 1e9
+                roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_launch=ab / tr["launches"],
+                                nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"])
+        out = {
+            "metric": "Mray/s (primary+bounce)", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: S(1000) spheres + SAH BVH, MIS, Policy.max_bounces=5 (primary+4 bounces), "
+                                   f"{spp} accumulations/step, 1024x1024 px per GPU", "image": f"{width}x{height}",
+                       "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
+                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU"},
+            "rays_per_step": rays_total / K,
+            "shadow_rays_per_step": (counts["shadow_rays"] / K) if counts else None,
+            "kernel_ms_per_step": {k: v["ms"] / K for k, v in ktimes.items() if v["launches"]},
+            "gather_ms": gather_ms,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(mirt, scene_fn, cfg, log)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

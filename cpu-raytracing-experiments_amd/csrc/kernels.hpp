@@ -151,8 +151,13 @@ MIRT_DI bool sphere_occludes(float4 s, float px, float py, float pz, float dx, f
 // arithmetic cannot change the result.  oracle/oracle.cpp mode 2 is the CPU twin of this routine.
 struct RaySlab { float ix, iy, iz, nx, ny, nz; };
 MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
+	// A zero (or denormal-small) direction component would make inv infinite and fma(plane, inf, -p*inf) = inf - inf = NaN.
+	// The box test only has to stay conservative, so such components get a huge finite reciprocal instead: the slab
+	// values keep the right sign and dwarf every finite t of the other axes.
 	RaySlab s;
-	s.ix = 1.0f / dx; s.iy = 1.0f / dy; s.iz = 1.0f / dz;
+	s.ix = (fabs_bits(dx) < 1e-30f) ? copysign_bits(1e30f, dx) : 1.0f / dx;
+	s.iy = (fabs_bits(dy) < 1e-30f) ? copysign_bits(1e30f, dy) : 1.0f / dy;
+	s.iz = (fabs_bits(dz) < 1e-30f) ? copysign_bits(1e30f, dz) : 1.0f / dz;
 	s.nx = -(px * s.ix); s.ny = -(py * s.iy); s.nz = -(pz * s.iz);
 	return s;
 }

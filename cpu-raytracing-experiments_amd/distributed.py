@@ -33,3 +33,19 @@ def gather_accumulator(local: torch.Tensor, n_tiles: int, rank: int, world: int,
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+class _DeviceMemory:
+    """Exposes a raw device allocation (the context's accumulator slab) through __cuda_array_interface__ so torch can
+    wrap it without a copy for the RCCL gather."""
+
+    def __init__(self, ptr: int, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr: int, nbytes: int, shape) -> torch.Tensor:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    assert n * 4 == nbytes, (shape, nbytes)
+    return torch.as_tensor(_DeviceMemory(ptr, shape), device="cuda")

@@ -672,8 +672,10 @@ static void bvh_pad(BVH& bvh, float pad_rel) {
 }
 struct RaySlab { float ix, iy, iz, nx, ny, nz; };
 static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
-	RaySlab s;
-	s.ix = 1.0f / dx; s.iy = 1.0f / dy; s.iz = 1.0f / dz;
+	RaySlab s;      // zero / denormal-small components get a huge finite reciprocal (see make_slab in csrc/kernels.hpp)
+	s.ix = (fast_abs(dx) < 1e-30f) ? fast_copysign(1e30f, dx) : 1.0f / dx;
+	s.iy = (fast_abs(dy) < 1e-30f) ? fast_copysign(1e30f, dy) : 1.0f / dy;
+	s.iz = (fast_abs(dz) < 1e-30f) ? fast_copysign(1e30f, dz) : 1.0f / dz;
 	s.nx = -(px * s.ix); s.ny = -(py * s.iy); s.nz = -(pz * s.iz);
 	return s;
 }

@@ -1,0 +1,276 @@
+"""GPU parity tests (-m gpu): every check calls the HIP path through the C-ABI (libmirt.so) and compares with the
+CPU oracle on the same seeded inputs — bit-exact for the integer/bit work AND for the f32 radiance (the kernels
+reproduce the reference's IEEE operation sequence), which is far inside north_star's 1e-4 relative tolerance.
+Full-size checks use size-independent properties (BVH == brute force, shard == whole, batch == sequential)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from test_oracle_cpu import CASES, GOLDEN, bits, make_scene
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4          # north_star tolerance; the assertions below are bit-exact and only fall back to this in messages
+
+
+def assert_same(got, want, what):
+    got = np.ascontiguousarray(got, dtype=np.float32); want = np.ascontiguousarray(want, dtype=np.float32)
+    if np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+        return
+    diff = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30)
+    bad = (got.view(np.uint32) != want.view(np.uint32)).sum()
+    raise AssertionError(f"{what}: {bad} of {got.size} words differ; max rel err {diff.max():.3e} (tolerance {REL_TOL})")
+
+
+@pytest.fixture(scope="module")
+def gpu(mirt):
+    r = mirt.Renderer(mirt.scene.default9(), device=0)
+    yield r
+    r.close()
+
+
+# ---- device math vs the oracle's unit functions ----------------------------------------------------------------
+def test_device_math_bit_exact(mirt, gpu, oracle_lib):
+    lib = oracle_lib
+    rng = np.random.default_rng(7)
+    n = 20000
+    # fast_sincos
+    x = np.concatenate([rng.uniform(0, 6.2832, n - 6), [0.0, 6.2831855, 3.1415927, 1e-38, -0.0, 100.0]]).astype(np.float32)
+    out = gpu.debug_math(0, x[None, :], 2)
+    s, c = C.c_float(), C.c_float()
+    for i in range(0, n, 1):
+        lib.orc_fast_sincos(float(x[i]), C.byref(s), C.byref(c))
+        assert np.float32(s.value).view(np.uint32) == out[0, i].view(np.uint32) and np.float32(c.value).view(np.uint32) == out[1, i].view(np.uint32), x[i]
+    # atan2 / asin
+    y = rng.uniform(-2, 2, n).astype(np.float32); xx = rng.uniform(-2, 2, n).astype(np.float32)
+    y[:4] = [0.0, -0.0, 1.0, 0.0]; xx[:4] = [0.0, -1.0, 0.0, 1.0]
+    out = gpu.debug_math(1, np.stack([y, xx]), 1)
+    want = np.array([lib.orc_fast_atan2(float(a), float(b)) for a, b in zip(y, xx)], dtype=np.float32)
+    assert_same(out[0], want, "fast_atan2")
+    xa = np.concatenate([rng.uniform(-1, 1, n - 4), [1.0, -1.0, 0.0, 1.25]]).astype(np.float32)
+    out = gpu.debug_math(2, xa[None, :], 1)
+    want = np.array([lib.orc_fast_asin(float(a)) for a in xa], dtype=np.float32)
+    assert_same(out[0], want, "fast_asin")
+    # IEEE division / sqrt on the device (correctly rounded, denormals kept)
+    a = np.concatenate([rng.uniform(-1e3, 1e3, n - 3), [1e-40, 3.0, 1e38]]).astype(np.float32)
+    b = np.concatenate([rng.uniform(-1e3, 1e3, n - 3), [3.0, 1e-40, 1e-3]]).astype(np.float32)
+    out = gpu.debug_math(3, np.stack([a, b]), 3)
+    with np.errstate(all="ignore"):
+        assert_same(out[0], np.float32(1.0) / a, "1/x")
+        assert_same(out[1], np.sqrt(np.abs(a)), "sqrt")
+        assert_same(out[2], a / b, "a/b")
+    # hemisphere, tangent frame, light sampling
+    t = rng.uniform(0, 1, n).astype(np.float32); u = rng.uniform(0, 1, n).astype(np.float32)
+    t[:2] = [1.0, 0.0]
+    out = gpu.debug_math(4, np.stack([t, u]), 3)
+    h = np.empty(3, dtype=np.float32)
+    for i in range(0, n, 5):
+        lib.orc_hemisphere(float(t[i]), float(u[i]), h.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(h.view(np.uint32), out[:, i].view(np.uint32))
+    N = rng.normal(size=(3, n)).astype(np.float32); N /= np.linalg.norm(N, axis=0, keepdims=True).astype(np.float32)
+    N[:, 0] = [0, 0, -1]; N[:, 1] = [0, 0, 1]
+    v = rng.normal(size=(3, n)).astype(np.float32)
+    out = gpu.debug_math(5, np.concatenate([N, v]), 10)
+    q = np.empty(4, dtype=np.float32); l = np.empty(3, dtype=np.float32); w = np.empty(3, dtype=np.float32)
+    for i in range(0, n, 5):
+        nn = np.ascontiguousarray(N[:, i]); vv = np.ascontiguousarray(v[:, i])
+        lib.orc_tangent_space(nn.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p))
+        lib.orc_to_local(q.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), l.ctypes.data_as(C.c_void_p))
+        lib.orc_to_world(q.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(np.concatenate([q, l, w]).view(np.uint32), out[:, i].view(np.uint32)), i
+    Wc = rng.normal(size=(3, n)).astype(np.float32); Wc /= np.linalg.norm(Wc, axis=0, keepdims=True).astype(np.float32)
+    dist = rng.uniform(0.2, 50, n).astype(np.float32); r2 = (rng.uniform(0.01, 0.15, n).astype(np.float32) * dist) ** 2
+    r2[: n // 4] = (np.float32(0.01) * dist[: n // 4]) ** 2                    # small-angle branch (sinThetaMax2 < 0.00068523)
+    sin2 = r2 / (dist * dist)
+    inp = np.concatenate([Wc, sin2[None], dist[None], r2[None], t[None], u[None]])
+    out = gpu.debug_math(6, inp, 5)
+    o5 = np.empty(5, dtype=np.float32)
+    for i in range(0, n, 5):
+        wc = np.ascontiguousarray(Wc[:, i])
+        lib.orc_sample_direction_to_sphere(wc.ctypes.data_as(C.c_void_p), float(sin2[i]), float(dist[i]), float(r2[i]), float(t[i]), float(u[i]), o5.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(o5.view(np.uint32), out[:, i].view(np.uint32)), i
+    # RNG
+    xs = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32); ys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    rg = rng.integers(1, 1000, n).astype(np.uint32)
+    xs[:3] = [1, 1, 5]; ys[:3] = [0, 33, 8455]
+    out = gpu.debug_math(7, np.stack([xs, ys, rg]).view(np.float32), 5).view(np.uint32)
+    assert out[0, 0] == 0xEF386249 and out[0, 1] == 0x56410662 and out[0, 2] == 0xD9B98C80
+    assert out[1:4, 0].view(np.float32).tolist() == [np.float32(0.1417161226272583), np.float32(0.9638892412185669), np.float32(0.3188127279281616)]
+    for i in range(0, n, 11):
+        st = C.c_uint32(lib.orc_hash_2d(int(xs[i]), int(ys[i])))
+        assert st.value == out[0, i]
+        f = [lib.orc_make_unit_float(lib.orc_pcg_generate(C.byref(st))) for _ in range(2)]
+        st2 = C.c_uint32(st.value)
+        f.append(lib.orc_make_unit_float(lib.orc_pcg_generate(C.byref(st))))
+        assert np.array_equal(np.array(f, dtype=np.float32).view(np.uint32), out[1:4, i])
+        assert lib.orc_rand_bounded_int(C.byref(st2), int(rg[i])) == out[4, i]
+
+
+# ---- single kernels ------------------------------------------------------------------------------------------------
+def test_raygen_bit_exact(mirt):
+    sc = mirt.scene.default9()
+    r = mirt.Renderer(sc, max_bounces=16); r.Resize(96, 64)
+    o = ob.Oracle(sc, max_bounces=16); o.Resize(96, 64)
+    for acc in (1, 2, 77):
+        gp, gd = r.debug_raygen(acc)
+        wp, wd = o.raygen(acc)
+        assert_same(gp, wp, "ray origins"); assert_same(gd, wd, "ray directions")
+    r.close()
+
+
+@pytest.mark.parametrize("scene_name,n_rays", [("default9", 40000), ("S1000a", 60000), ("S8a", 20000)])
+def test_trace_kernels_bit_exact(mirt, scene_name, n_rays):
+    sc = make_scene(mirt, scene_name)
+    o = ob.Oracle(sc); o.Resize(128, 128)
+    cp, cd = o.raygen(1)
+    rng = np.random.default_rng(3)
+    # camera rays + incoherent rays from points near sphere surfaces (incl. inside, on the surface, far away)
+    geo = sc.geometry
+    pick = rng.integers(0, len(geo), n_rays)
+    nrm = rng.normal(size=(n_rays, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rad = np.sqrt(geo["radius_sq"][pick])[:, None] * rng.choice([0.5, 1.0, 1.0 + 1e-4, 1.5, 3.0], size=(n_rays, 1))
+    p = (geo["position"][pick] + nrm * rad).astype(np.float32).T
+    d = rng.normal(size=(n_rays, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32).T
+    d[0, :5] = 0.0                                          # axis-parallel rays: 1/0 slabs
+    P = np.ascontiguousarray(np.concatenate([cp, p], axis=1)); D = np.ascontiguousarray(np.concatenate([cd, d], axis=1))
+    wt, wi = o.trace_closest(P, D, ob.TRAV_BRUTE)
+    tmax = np.where(wi >= 0, wt * rng.uniform(0.5, 1.5, wt.shape), 10.0).astype(np.float32)
+    wo = o.trace_shadow(P, D, tmax, ob.TRAV_BRUTE)
+    for use_bvh in (0, 1):
+        r = mirt.Renderer(sc, use_bvh=bool(use_bvh))
+        gt, gi = r.debug_trace_closest(P, D)
+        assert np.array_equal(gi, wi), f"primID mismatch use_bvh={use_bvh}: {(gi != wi).sum()}"
+        assert_same(gt, wt, f"tfar use_bvh={use_bvh}")
+        go = r.debug_trace_shadow(P, D, tmax)
+        assert np.array_equal(go, wo), f"occlusion mismatch use_bvh={use_bvh}: {(go != wo).sum()}"
+        r.close()
+    assert (wi >= 0).mean() > 0.2
+
+
+# ---- the whole path against the golden vectors and the live oracle -----------------------------------------------------
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_accumulate_matches_golden(mirt, name, use_bvh):
+    cfg = CASES[name]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    r = mirt.Renderer(make_scene(mirt, cfg["scene"]), max_bounces=cfg["mb"], buckets=cfg.get("buckets", 5), mis=cfg.get("mis", True), use_bvh=use_bvh)
+    r.Resize(cfg["w"], cfg["h"])
+    r.Accumulate(cfg["spp"])
+    assert r.accumulations == cfg["spp"]
+    assert_same(r.accumulator(), g["accumulator"], f"{name} accumulator")
+    ready = r.Render()
+    if g["frame"].size:
+        assert ready
+        assert_same(r.GetFrame(), g["frame"], f"{name} frame")
+    else:
+        assert not ready and not r.GetFrame().any()          # Renderer.hpp:437: no output until accumulations % 5 == 0
+    c = r.counters()
+    assert c["rays"] == int(g["rays"]) and c["terminated"] == int(g["terminated"])
+    assert c["terminated"] + c["dropped"] == cfg["spp"] * (cfg["w"] // 16) * (cfg["h"] // 16) * 256
+    r.close()
+
+
+@pytest.mark.parametrize("scene_name,w,h,spp,mb", [("default9", 160, 96, 15, 16), ("S1000a", 256, 128, 10, 5), ("S8a", 512, 512, 1, 2)])
+def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
+    sc = make_scene(mirt, scene_name)
+    o = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+    r = mirt.Renderer(sc, max_bounces=mb, use_bvh=(scene_name != "S8a"), count_traffic=True); r.Resize(w, h); r.Accumulate(spp)
+    assert_same(r.accumulator(), o.accumulator(), "accumulator")
+    if spp % 5 == 0:
+        assert r.Render(); assert_same(r.GetFrame(), o.Render(), "frame")
+    co, cg = o.counters(), r.counters()
+    assert cg["rays"] == co["rays"] and cg["terminated"] == co["terminated"]
+    if scene_name != "S8a":
+        # same traversal algorithm as the oracle's mode 2 -> same visit counts (feeds the roofline's algorithmic bytes)
+        t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.Resize(w, h); t.Accumulate(spp)
+        ct = t.counters()
+        assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
+    r.close()
+
+
+def test_white_furnace_gpu(mirt):
+    r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
+    assert np.all(r.accumulator() == 1.0)
+    assert r.Render() and np.ptp(r.GetFrame()[..., :3].reshape(-1, 3), axis=0).max() == 0.0
+    r.close()
+
+
+# ---- size-independent properties at larger sizes ---------------------------------------------------------------------------
+def test_bvh_equals_brute_force_on_gpu_cfg2_shape(mirt):
+    """BASELINE cfg2 geometry (1024x1024, 1k spheres, 5 bounce iterations) at 5 accumulations: the BVH path must give
+    the brute-force path's accumulators bit for bit (10 M rays)."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    out = []
+    for use_bvh in (False, True):
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=use_bvh); r.Resize(1024, 1024); r.Accumulate(5)
+        out.append((r.accumulator(), r.counters())); r.close()
+    assert_same(out[1][0], out[0][0], "BVH vs brute force")
+    assert out[0][1]["rays"] == out[1][1]["rays"] > 10_000_000
+
+
+def test_sharded_contexts_reproduce_the_whole(mirt):
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    w, h, spp = 256, 192, 10
+    whole = mirt.Renderer(sc, max_bounces=5, use_bvh=True); whole.Resize(w, h); whole.Accumulate(spp)
+    want = whole.accumulator(); whole.close()
+    tiles = (w // 16) * (h // 16)
+    parts = []
+    for rank in range(3):
+        first, count = mirt.distributed.tile_range(tiles, rank, 3)
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True); r.Resize(w, h); r.SetTileRange(first, count); r.Accumulate(spp)
+        parts.append(r.accumulator()); r.close()
+    assert_same(np.concatenate(parts), want, "sharded vs whole")
+
+
+def test_batching_and_call_splitting_do_not_change_results(mirt):
+    sc = mirt.scene.default9()
+    a = mirt.Renderer(sc, use_bvh=True); a.Resize(128, 64); a.Accumulate(13)
+    b = mirt.Renderer(sc, use_bvh=True, max_batch=1); b.Resize(128, 64)
+    for n in (1, 4, 0, 8):
+        b.Accumulate(n)
+    assert a.accumulations == b.accumulations == 13
+    assert_same(b.accumulator(), a.accumulator(), "batch 1 vs batch 5")
+    assert not a.Render()                                  # 13 % 5 != 0
+    a.Accumulate(2); assert a.Render()
+    a.close(); b.close()
+
+
+def test_resume_from_loaded_accumulator(mirt):
+    sc = mirt.scene.default9()
+    a = mirt.Renderer(sc); a.Resize(64, 64); a.Accumulate(10)
+    b = mirt.Renderer(sc); b.Resize(64, 64); b.Accumulate(5)
+    c = mirt.Renderer(sc); c.Resize(64, 64); c.load_accumulator(b.accumulator(), 5); c.Accumulate(5)
+    assert_same(c.accumulator(), a.accumulator(), "resume")
+    a.ResetAccumulator()
+    assert a.accumulations == 0 and not a.accumulator().any()
+    for r in (a, b, c):
+        r.close()
+
+
+def test_edge_cases_and_errors(mirt):
+    sc = mirt.scene.default9()
+    r = mirt.Renderer(sc)
+    with pytest.raises(mirt.MirtError):
+        r.Accumulate(1)                                    # Resize not called
+    r.Resize(70, 40)                                       # truncates to 4 x 2 tiles (Renderer.hpp:59-60)
+    r.Accumulate(5)
+    assert r.accumulator().shape == (8, 5, 3, 256)
+    assert r.Render()
+    fb = r.GetFrame()
+    assert fb.shape == (40, 70, 4) and not fb[32:].any() and not fb[:, 64:].any() and np.all(fb[:32, :64, 3] == 1.0)
+    o = ob.Oracle(sc); o.Resize(70, 40); o.Accumulate(5)
+    assert_same(r.accumulator(), o.accumulator(), "ragged size")
+    with pytest.raises(mirt.MirtError):
+        r.set_policy(buckets=0)
+    with pytest.raises(mirt.MirtError):
+        r.SetTileRange(7, 5)
+    r.Resize(8, 8)                                         # no whole tile: nothing to do, no crash
+    with pytest.raises(mirt.MirtError):
+        r.Accumulate(1)
+    r.close()
+    bad = mirt.scene.default9(); bad.geometry["material_ID"][3] = 99
+    with pytest.raises(mirt.MirtError):
+        mirt.Renderer(bad)
