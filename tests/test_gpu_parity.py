@@ -274,3 +274,33 @@ def test_edge_cases_and_errors(mirt):
     bad = mirt.scene.default9(); bad.geometry["material_ID"][3] = 99
     with pytest.raises(mirt.MirtError):
         mirt.Renderer(bad)
+
+
+def test_cpp_host_matches_python_host(mirt, tmp_path):
+    """The C++ host mirror (csrc/mirt_host.hpp + mirt_headless, reference call protocol: Accumulate();Render() per frame)
+    must produce the same accumulator as the Python host — both only marshal the scene into the same C-ABI."""
+    import json
+    import subprocess
+    exe = os.path.join(mirt.CSRC, "mirt_headless")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", mirt.CSRC, "mirt_headless"], check=True)
+
+    def fnv(acc):
+        h = 1469598103934665603
+        for b in np.ascontiguousarray(acc, dtype=np.float32).view(np.uint8).ravel().tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    for args, sc, w, hgt, spp, mb in [(["--scene", "default9"], mirt.scene.default9(), 64, 48, 10, 16),
+                                      (["--scene", "synthetic:1000", "--ambient", "0.5", "--bounces", "5"], mirt.scene.synthetic(1000, ambient=0.5), 64, 32, 5, 5)]:
+        pfm = str(tmp_path / "frame.pfm")
+        out = subprocess.run([exe, *args, "--size", f"{w}x{hgt}", "--spp", str(spp), "--out", pfm], check=True, capture_output=True, text=True).stdout
+        rep = json.loads(out)
+        r = mirt.Renderer(sc, max_bounces=mb, use_bvh=True); r.Resize(w, hgt); r.Accumulate(spp); assert r.Render()
+        assert rep["accumulations"] == spp and rep["rays"] == r.counters()["rays"] and rep["frame_ready"]
+        assert rep["accumulator_fnv1a"] == fnv(r.accumulator())
+        raw = open(pfm, "rb").read()
+        assert raw.startswith(b"PF\n") and len(raw) == len(f"PF\n{w} {hgt}\n-1.0\n") + w * hgt * 12
+        img = np.frombuffer(raw[-w * hgt * 12:], dtype="<f4").reshape(hgt, w, 3)
+        assert np.array_equal(img, r.GetFrame()[..., :3])
+        r.close()
