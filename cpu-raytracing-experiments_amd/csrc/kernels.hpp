@@ -24,7 +24,9 @@
 namespace mirt {
 
 constexpr uint32_t kBlock = 256;
-constexpr uint32_t kTraceBlock = 512;           // trace kernels: bigger workgroups amortise the LDS staging of the BVH
+constexpr uint32_t kShadeBlock = 1024;          // shade: one compaction atomic per stream per 1024 rays
+constexpr uint32_t kTraceBlock = 1024;          // trace kernels: one workgroup per CU stages the BVH into LDS once per launch
+constexpr uint32_t kLdsStack = 16;              // traversal-stack entries per lane kept in LDS (deeper ones spill to scratch)
 constexpr uint32_t kLeafBit = 0x80000000u;      // child reference flag (bvh_layout.hpp)
 constexpr uint32_t kTileSize = 256;
 constexpr uint32_t kTileRoot = 16;
@@ -109,6 +111,33 @@ MIRT_DI void wave_sum(uint32_t v, unsigned long long* counter) {
 	if (lane_id() == 0 && v) atomicAdd(counter, static_cast<unsigned long long>(v));
 }
 
+// Two-stream compaction for a whole workgroup: wave64 ballots give per-wave counts, one lane per stream adds the
+// workgroup total to the stream counter (ONE global atomic per stream per `blockDim.x` rays — same-address returning
+// atomics serialise at ~11 ns each, which dominated the first version of k_shade), and every lane gets
+// base + (counts of earlier waves) + (rank inside its wave).  Must be called by all threads of the block, converged.
+// `scratch` = 2*2*16+2*2 words of LDS, double-buffered on `parity` so consecutive calls need no third barrier.
+MIRT_DI void block_append2(bool flag_a, bool flag_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t* scratch, uint32_t parity,
+                           uint32_t& slot_a, uint32_t& slot_b) {
+	const unsigned long long ma = __ballot(flag_a), mb = __ballot(flag_b);
+	const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = lane_id();
+	uint32_t* cnt_a = scratch + parity * 36u;       // [16] a, [16] b, base a, base b, pad
+	uint32_t* cnt_b = cnt_a + 16u;
+	uint32_t* base = cnt_a + 32u;
+	if (lane == 0) { cnt_a[wave] = static_cast<uint32_t>(__popcll(ma)); cnt_b[wave] = static_cast<uint32_t>(__popcll(mb)); }
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		const uint32_t* cnt = threadIdx.x ? cnt_b : cnt_a;
+		uint32_t total = 0;
+		for (uint32_t w = 0; w < n_waves; w++) total += cnt[w];
+		base[threadIdx.x] = total ? atomicAdd(threadIdx.x ? counter_b : counter_a, total) : 0u;
+	}
+	__syncthreads();
+	uint32_t pa = base[0], pb = base[1];
+	for (uint32_t w = 0; w < wave; w++) { pa += cnt_a[w]; pb += cnt_b[w]; }
+	slot_a = pa + mask_rank(ma);
+	slot_b = pb + mask_rank(mb);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Intersection arithmetic
 // ------------------------------------------------------------------------------------------------
@@ -177,20 +206,31 @@ MIRT_DI void sphere_closest_tie(float4 s, int32_t prim, float px, float py, floa
 	if (t < tfar || (t == tfar && (primID < 0 || prim < primID))) { tfar = t; primID = prim; }
 }
 
-struct TraceLds { const float4* recs; const float4* spheres; };
+// LDS views are typed with address_space(3) so every access is a ds_read/ds_write.  (With generic pointers hipcc merged
+// the "staged record" and "record in HBM" paths into one pointer select + flat_load_dwordx4, which is several times
+// slower than ds_read_b128 and waits on both vmcnt and lgkmcnt.)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] words
+MIRT_DI float4 to_float4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
 
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool ALL_LDS>
 MIRT_DI bool traverse_bvh(const SceneDev& sc, const TraceLds lds, float px, float py, float pz, float dx, float dy, float dz,
                           float& tfar, int32_t& primID, uint32_t& n_nodes, uint32_t& n_spheres) {
 	if (sc.n_recs == 0) return false;
 	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
-	uint32_t stack[kStack];
+	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread], so a wave's accesses to one
+	// depth are consecutive words: conflict-free); only deeper entries touch the scratch array.
+	uint32_t spill[kStack - kLdsStack];
+	lds_u32* const lstack = lds.stack + threadIdx.x;
+	const uint32_t lstride = blockDim.x;
 	uint32_t sp = 0;
 	uint32_t cur = 0;
 	for (;;) {
-		float4 q0, q1, q2, q3;
-		if (cur < sc.lds_recs) { const float4* r = lds.recs + 4u * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
-		else { const float4* r = sc.recs + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+		v4f q0, q1, q2, q3;
+		if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + 4u * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
 		if (COUNT) n_nodes += 2;
 		float ta, tb;
 		bool ha = slab_hit(__builtin_fmaf(q0.x, rs.ix, rs.nx), __builtin_fmaf(q0.z, rs.ix, rs.nx),
@@ -209,7 +249,8 @@ MIRT_DI bool traverse_bvh(const SceneDev& sc, const TraceLds lds, float px, floa
 				const uint32_t first = c & 0xffffffu, count = ((c >> 24) & 0x7fu) + 1u;
 				for (uint32_t p = first; p < first + count; p++) {
 					if (COUNT) n_spheres++;
-					const float4 s = (p < sc.lds_spheres) ? lds.spheres[p] : sc.spheres[p];
+					float4 s;
+					if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
 					if (ANYHIT) { if (sphere_occludes(s, px, py, pz, dx, dy, dz, tfar)) return true; }
 					else sphere_closest_tie(s, static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
 				}
@@ -219,14 +260,17 @@ MIRT_DI bool traverse_bvh(const SceneDev& sc, const TraceLds lds, float px, floa
 		if (!ANYHIT) { ha = ha && ta <= tfar; hb = hb && tb <= tfar; }          // re-check against the shrunken tfar
 		if (ha && hb) {
 			const bool a_first = ANYHIT ? true : (ta <= tb);
-			if (sp < kStack) stack[sp++] = a_first ? c1 : c0;                     // depth < 64 is validated on the host
+			const uint32_t far = a_first ? c1 : c0;                                // depth < 64 is validated on the host
+			if (sp < kLdsStack) lstack[sp * lstride] = far; else if (sp < kStack) spill[sp - kLdsStack] = far;
+			sp++;
 			cur = a_first ? c0 : c1;
 			continue;
 		}
 		if (ha) { cur = c0; continue; }
 		if (hb) { cur = c1; continue; }
 		if (sp == 0) break;
-		cur = stack[--sp];
+		--sp;
+		cur = (sp < kLdsStack) ? lstack[sp * lstride] : spill[sp - kLdsStack];
 	}
 	return false;
 }
@@ -255,15 +299,19 @@ MIRT_DI bool traverse_brute(const SceneDev& sc, float4* lds, bool active, float 
 	return occluded;
 }
 
-// Dynamic LDS of the trace kernels: [records 0..lds_recs) | spheres 0..lds_spheres)] for the BVH path,
-// or one kBruteChunk sphere buffer for the brute-force path.
-MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds) {
+// Dynamic LDS of the trace kernels: [records 0..lds_recs) | spheres 0..lds_spheres) | stack kLdsStack x blockDim] for
+// the BVH path, or one kBruteChunk sphere buffer for the brute-force path.
+MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds_generic) {
+	lds_v4f* lds = (lds_v4f*)lds_generic;
+	const v4f* recs = reinterpret_cast<const v4f*>(sc.recs);
+	const v4f* sph = reinterpret_cast<const v4f*>(sc.spheres);
 	const uint32_t nq = sc.lds_recs * 4u;
-	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[j] = sc.recs[j];
-	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sc.spheres[j];
+	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[j] = recs[j];
+	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sph[j];
 	__syncthreads();
-	return TraceLds{ lds, lds + nq };
+	return TraceLds{ lds, lds + nq, (lds_u32*)(lds + nq + sc.lds_spheres) };
 }
+MIRT_DI bool bvh_all_in_lds(const SceneDev& sc) { return sc.lds_recs == sc.n_recs && sc.lds_spheres == sc.n_spheres; }
 
 // ------------------------------------------------------------------------------------------------
 // RAY GENERATION — Renderer.hpp:97-127 (stream init is implicit: radiance 0 / throughput 1 are
@@ -305,8 +353,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, Stre
 	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, static_cast<unsigned long long>(n));
 	if (blockIdx.x * kTraceBlock >= n) return;                       // whole workgroup idle: skip the staging too
 	uint32_t c_nodes = 0, c_spheres = 0;
-	TraceLds tl{ lds, lds };
+	TraceLds tl{ nullptr, nullptr, nullptr };
 	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	const bool all_lds = bvh_all_in_lds(sc);
 	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
 		const uint32_t i = base + threadIdx.x;
 		const bool active = i < n;
@@ -315,7 +364,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, Stre
 		float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
 		int32_t prim = -1;
 		if (sc.use_bvh) {
-			if (active) traverse_bvh<false, COUNT>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
+			if (active) {
+				if (all_lds) traverse_bvh<false, COUNT, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
+				else traverse_bvh<false, COUNT, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
+			}
 		} else {
 			traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
 		}
@@ -352,7 +404,7 @@ MIRT_DI f3 sky_eval(const SceneDev& sc, float x, float y, float z) {
 // (Renderer.hpp:169-431).  FIRST = bounce 0: radiance 0, throughput 1 (Renderer.hpp:98-101) without reading them.
 // ------------------------------------------------------------------------------------------------
 template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
+__global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
                                                   const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
                                                   uint32_t* stream_count, uint32_t* shadow_count, float* __restrict__ accum, DevCounters* ctr) {
 	const uint32_t n = stream_count[bounce];
@@ -360,8 +412,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, FrameParams fp, S
 	uint32_t* sh_count = &shadow_count[bounce];
 	const bool last_bounce = !(bounce < fp.max_bounces - 1u);                 // Renderer.hpp:358
 	const float light_selection_pdf = 1.0f / static_cast<float>(fp.n_lights);  // Renderer.hpp:78
+	__shared__ uint32_t append_scratch[72];
+	uint32_t c_term = 0, c_drop = 0, parity = 0;
 
-	for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+	for (uint32_t base = blockIdx.x * kShadeBlock; base < n; base += gridDim.x * kShadeBlock, parity ^= 1u) {
 		const uint32_t i = base + threadIdx.x;
 		const bool active = i < n;
 		bool survive = false, has_shadow = false, terminated = false, dropped = false;
@@ -476,9 +530,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, FrameParams fp, S
 				}
 			}
 		}
-		// ---- stream compaction: wave64 ballot + mbcnt prefix, one atomic per wave and stream ----
-		const uint32_t slot = wave_append(survive, next_count);
-		const uint32_t sslot = wave_append(has_shadow, sh_count);
+		// ---- stream compaction: wave64 ballot + mbcnt prefix inside each wave, one atomic per workgroup and stream ----
+		uint32_t slot, sslot;
+		block_append2(survive, has_shadow, next_count, sh_count, append_scratch, parity, slot, sslot);
 		if (survive) {
 			out.px[slot] = P.x; out.py[slot] = P.y; out.pz[slot] = P.z;
 			out.dx[slot] = ndir.x; out.dy[slot] = ndir.y; out.dz[slot] = ndir.z;
@@ -500,9 +554,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneDev sc, FrameParams fp, S
 			if (survive) { out.rr[slot] = Rf.x; out.rg[slot] = Rf.y; out.rb[slot] = Rf.z; }
 			else accumulate_add(accum, accum_index(fp, path), Rf.x, Rf.y, Rf.z);   // ACCUMULATION, Renderer.hpp:424-430
 		}
-		wave_count(terminated && !has_shadow, &ctr->terminated);
-		wave_count(dropped, &ctr->dropped);
+		c_term += (terminated && !has_shadow) ? 1u : 0u;
+		c_drop += dropped ? 1u : 0u;
 	}
+	wave_sum(c_term, &ctr->terminated);
+	wave_sum(c_drop, &ctr->dropped);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,9 +572,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, Frame
 	if (n == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(n));
 	if (blockIdx.x * kTraceBlock >= n) return;
-	uint32_t c_nodes = 0, c_spheres = 0;
-	TraceLds tl{ lds, lds };
+	uint32_t c_nodes = 0, c_spheres = 0, c_term = 0;
+	TraceLds tl{ nullptr, nullptr, nullptr };
 	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	const bool all_lds = bvh_all_in_lds(sc);
 	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
 		const uint32_t i = base + threadIdx.x;
 		const bool active = i < n;
@@ -527,21 +584,21 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, Frame
 		bool occluded = false;
 		int32_t dummy = -1;
 		if (sc.use_bvh) {
-			if (active) occluded = traverse_bvh<true, COUNT>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres);
+			if (active) occluded = all_lds ? traverse_bvh<true, COUNT, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres)
+			                               : traverse_bvh<true, COUNT, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres);
 		} else {
 			occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c_spheres);
 		}
-		bool to_accum = false;
 		if (active) {
 			f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
 			if (!occluded) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }     // Renderer.hpp:307-311
 			R.x += sh.er[i]; R.y += sh.eg[i]; R.z += sh.eb[i];                        // Renderer.hpp:339-341 / 348-350
 			const uint32_t dest = sh.dest[i];
-			if (dest & kDestAccum) { to_accum = true; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
+			if (dest & kDestAccum) { c_term++; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
 			else { out.rr[dest] = R.x; out.rg[dest] = R.y; out.rb[dest] = R.z; }
 		}
-		wave_count(to_accum, &ctr->terminated);
 	}
+	wave_sum(c_term, &ctr->terminated);
 	if (COUNT) { wave_sum(c_nodes, &ctr->shadow_nodes); wave_sum(c_spheres, &ctr->shadow_spheres); }
 }
 
@@ -582,15 +639,17 @@ __global__ __launch_bounds__(kTraceBlock) void k_debug_shadow(SceneDev sc, const
 	extern __shared__ float4 lds[];
 	uint32_t c0 = 0, c1 = 0;
 	if (blockIdx.x * kTraceBlock >= n) return;
-	TraceLds tl{ lds, lds };
+	TraceLds tl{ nullptr, nullptr, nullptr };
 	if (sc.use_bvh) tl = stage_bvh(sc, lds);
+	const bool all_lds = bvh_all_in_lds(sc);
 	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
 		const uint32_t i = base + threadIdx.x;
 		const bool active = i < n;
 		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
 		if (active) { px = p[i]; py = p[n + i]; pz = p[2 * n + i]; dx = d[i]; dy = d[n + i]; dz = d[2 * n + i]; tfar = tfar_in[i]; }
 		bool o = false; int32_t dummy = -1;
-		if (sc.use_bvh) { if (active) o = traverse_bvh<true, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1); }
+		if (sc.use_bvh) { if (active) o = all_lds ? traverse_bvh<true, false, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1)
+		                                            : traverse_bvh<true, false, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1); }
 		else o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
 		if (active) occ[i] = o ? 1 : 0;
 	}

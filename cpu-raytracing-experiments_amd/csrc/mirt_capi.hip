@@ -109,11 +109,12 @@ uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
 // Trace kernels are launched as a resident grid (as many 512-thread workgroups as their LDS footprint lets a
 // CU hold) and grid-stride over the stream, so each workgroup stages the BVH into LDS once per launch.
 constexpr uint32_t kLdsPerCu = 160u * 1024u;
-constexpr uint32_t kLdsStageBudget = 80u * 1024u;      // two workgroups (16 waves) per CU
-uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? std::max<uint32_t>(c->trace_lds_bytes, 16u) : kBruteChunk * 16u; }
+constexpr uint32_t kLdsStackBytes = kLdsStack * kTraceBlock * 4u;   // 64 KB: 16 stack entries for each of 1024 lanes
+constexpr uint32_t kLdsStageBudget = 96u * 1024u;      // staged BVH bytes; + the stack = one 16-wave workgroup per CU
+uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? c->trace_lds_bytes + kLdsStackBytes : kBruteChunk * 16u; }
 uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 	uint32_t per_cu = kLdsPerCu / trace_lds(c);
-	if (per_cu > 4) per_cu = 4;                                       // 4 x 512 threads = 32 waves, the CU's limit
+	if (per_cu > 2) per_cu = 2;                                       // 2 x 1024 threads = 32 waves, the CU's limit
 	if (per_cu < 1) per_cu = 1;
 	uint64_t blocks = (work_items + kTraceBlock - 1) / kTraceBlock;
 	const uint64_t cap = static_cast<uint64_t>(c->n_cu) * per_cu;
@@ -228,6 +229,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const bool count = c->policy.count_traffic != 0;
 	const uint32_t grid = grid_for(c, total);
 	const uint32_t tgrid = trace_grid(c, total);
+	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
 	const uint32_t tlds = trace_lds(c);
 
 	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 2 + 2) * sizeof(uint32_t), c->stream));
@@ -240,8 +242,8 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr);
 		  else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr); }
 		{ Bracket t(c, MIRT_K_SHADE);
-		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
-		  else             hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
+		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
+		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
 		if (fp.mis && bounce + 1 < nb) {
 			Bracket t(c, MIRT_K_SHADOW);
 			if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, fp, c->shadow_buf, out, bounce, shadow_count, accum, ctr);
@@ -371,7 +373,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
 	if (static_cast<uint64_t>(n_recs) * 64u + static_cast<uint64_t>(n_spheres) * 16u <= kLdsStageBudget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
-	else { s.lds_recs = std::min<uint32_t>(n_recs, (kLdsStageBudget - 16u * 1024u) / 64u); s.lds_spheres = 0; }
+	else { s.lds_recs = std::min<uint32_t>(n_recs, kLdsStageBudget / 64u); s.lds_spheres = 0; }
 	c->trace_lds_bytes = s.lds_recs * 64u + s.lds_spheres * 16u;
 	{
 		const int lds_max = static_cast<int>(kLdsPerCu);
