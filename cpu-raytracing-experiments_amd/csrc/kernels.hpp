@@ -215,64 +215,153 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] words
 MIRT_DI float4 to_float4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
 
+// One lane's traversal state.  A lane keeps it in registers across refills of OTHER lanes (persistent waves below).
+struct Trav {
+	float px, py, pz, dx, dy, dz;
+	RaySlab rs;
+	float tfar;
+	int32_t prim;
+	uint32_t cur, sp;
+};
+// Stack entries beyond the LDS-resident ones.  Kept OUTSIDE Trav: a dynamically indexed member would pin the whole struct
+// in scratch memory (every step would then reload the ray through VMEM); alone, only this rarely-touched array lives there.
+struct TravSpill { uint32_t e[kStack - kLdsStack]; };
+MIRT_DI void trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar) {
+	t.px = px; t.py = py; t.pz = pz; t.dx = dx; t.dy = dy; t.dz = dz;
+	t.rs = make_slab(px, py, pz, dx, dy, dz);
+	t.tfar = tfar; t.prim = -1; t.cur = 0; t.sp = 0;
+}
+// One step = one 64-B record: slab-test both children against the current tfar, intersect hit leaf children at once,
+// re-check inner children against the shrunken tfar, enter the nearer, push the other (or pop).  Returns true when this
+// ray is finished (stack empty, or ANYHIT occluder found -> occluded = true).
 template <bool ANYHIT, bool COUNT, bool ALL_LDS>
-MIRT_DI bool traverse_bvh(const SceneDev& sc, const TraceLds lds, float px, float py, float pz, float dx, float dy, float dz,
-                          float& tfar, int32_t& primID, uint32_t& n_nodes, uint32_t& n_spheres) {
-	if (sc.n_recs == 0) return false;
-	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
-	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread], so a wave's accesses to one
-	// depth are consecutive words: conflict-free); only deeper entries touch the scratch array.
-	uint32_t spill[kStack - kLdsStack];
+MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres) {
+	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
+	// are consecutive words, conflict-free); deeper entries (rare) use a scratch array.
 	lds_u32* const lstack = lds.stack + threadIdx.x;
 	const uint32_t lstride = blockDim.x;
-	uint32_t sp = 0;
-	uint32_t cur = 0;
-	for (;;) {
-		v4f q0, q1, q2, q3;
-		if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + 4u * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
-		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
-		if (COUNT) n_nodes += 2;
-		float ta, tb;
-		bool ha = slab_hit(__builtin_fmaf(q0.x, rs.ix, rs.nx), __builtin_fmaf(q0.z, rs.ix, rs.nx),
-		                   __builtin_fmaf(q1.x, rs.iy, rs.ny), __builtin_fmaf(q1.z, rs.iy, rs.ny),
-		                   __builtin_fmaf(q2.x, rs.iz, rs.nz), __builtin_fmaf(q2.z, rs.iz, rs.nz), tfar, ta);
-		bool hb = slab_hit(__builtin_fmaf(q0.y, rs.ix, rs.nx), __builtin_fmaf(q0.w, rs.ix, rs.nx),
-		                   __builtin_fmaf(q1.y, rs.iy, rs.ny), __builtin_fmaf(q1.w, rs.iy, rs.ny),
-		                   __builtin_fmaf(q2.y, rs.iz, rs.nz), __builtin_fmaf(q2.w, rs.iz, rs.nz), tfar, tb);
-		const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-		// hit leaf children are resolved on the spot (no stack traffic; shrinks tfar before descending)
+	const uint32_t cur = t.cur;
+	v4f q0, q1, q2, q3;
+	if (ALL_LDS || cur < sc.lds_recs) {     // staged records are stored plane-major (q0[], q1[], q2[], q3[]): 16-B stride between lanes' addresses
+		const lds_v4f* r = lds.recs + cur; const uint32_t ns = sc.lds_recs;
+		q0 = r[0]; q1 = r[ns]; q2 = r[2u * ns]; q3 = r[3u * ns];
+	}
+	else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+	if (COUNT) n_nodes += 2;
+	const RaySlab& rs = t.rs;
+	float ta, tb;
+	bool ha = slab_hit(__builtin_fmaf(q0.x, rs.ix, rs.nx), __builtin_fmaf(q0.z, rs.ix, rs.nx),
+	                   __builtin_fmaf(q1.x, rs.iy, rs.ny), __builtin_fmaf(q1.z, rs.iy, rs.ny),
+	                   __builtin_fmaf(q2.x, rs.iz, rs.nz), __builtin_fmaf(q2.z, rs.iz, rs.nz), t.tfar, ta);
+	bool hb = slab_hit(__builtin_fmaf(q0.y, rs.ix, rs.nx), __builtin_fmaf(q0.w, rs.ix, rs.nx),
+	                   __builtin_fmaf(q1.y, rs.iy, rs.ny), __builtin_fmaf(q1.w, rs.iy, rs.ny),
+	                   __builtin_fmaf(q2.y, rs.iz, rs.nz), __builtin_fmaf(q2.w, rs.iz, rs.nz), t.tfar, tb);
+	const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
 #pragma unroll
-		for (int k = 0; k < 2; k++) {
-			const uint32_t c = k ? c1 : c0;
-			const bool h = k ? hb : ha;
-			if (h && (c & kLeafBit)) {
-				const uint32_t first = c & 0xffffffu, count = ((c >> 24) & 0x7fu) + 1u;
-				for (uint32_t p = first; p < first + count; p++) {
-					if (COUNT) n_spheres++;
-					float4 s;
-					if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
-					if (ANYHIT) { if (sphere_occludes(s, px, py, pz, dx, dy, dz, tfar)) return true; }
-					else sphere_closest_tie(s, static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
-				}
+	for (int k = 0; k < 2; k++) {
+		const uint32_t c = k ? c1 : c0;
+		const bool h = k ? hb : ha;
+		if (h && (c & kLeafBit)) {
+			const uint32_t first = c & 0xffffffu, count = ((c >> 24) & 0x7fu) + 1u;
+			for (uint32_t p = first; p < first + count; p++) {
+				if (COUNT) n_spheres++;
+				float4 s;
+				if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
+				if (ANYHIT) { if (sphere_occludes(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar)) { occluded = true; return true; } }
+				else sphere_closest_tie(s, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 			}
 		}
-		ha = ha && !(c0 & kLeafBit); hb = hb && !(c1 & kLeafBit);
-		if (!ANYHIT) { ha = ha && ta <= tfar; hb = hb && tb <= tfar; }          // re-check against the shrunken tfar
-		if (ha && hb) {
-			const bool a_first = ANYHIT ? true : (ta <= tb);
-			const uint32_t far = a_first ? c1 : c0;                                // depth < 64 is validated on the host
-			if (sp < kLdsStack) lstack[sp * lstride] = far; else if (sp < kStack) spill[sp - kLdsStack] = far;
-			sp++;
-			cur = a_first ? c0 : c1;
-			continue;
-		}
-		if (ha) { cur = c0; continue; }
-		if (hb) { cur = c1; continue; }
-		if (sp == 0) break;
-		--sp;
-		cur = (sp < kLdsStack) ? lstack[sp * lstride] : spill[sp - kLdsStack];
 	}
+	ha = ha && !(c0 & kLeafBit); hb = hb && !(c1 & kLeafBit);
+	if (!ANYHIT) { ha = ha && ta <= t.tfar; hb = hb && tb <= t.tfar; }          // re-check against the shrunken tfar
+	if (ha && hb) {
+		const bool a_first = ANYHIT ? true : (ta <= tb);
+		const uint32_t far = a_first ? c1 : c0;                                // depth < 64 is validated on the host
+		if (t.sp < kLdsStack) lstack[t.sp * lstride] = far; else if (t.sp < kStack) spill.e[t.sp - kLdsStack] = far;
+		t.sp++;
+		t.cur = a_first ? c0 : c1;
+		return false;
+	}
+	if (ha) { t.cur = c0; return false; }
+	if (hb) { t.cur = c1; return false; }
+	if (t.sp == 0) return true;
+	--t.sp;
+	if (t.sp < kLdsStack) t.cur = lstack[t.sp * lstride]; else t.cur = spill.e[t.sp - kLdsStack];
 	return false;
+}
+
+// ---- persistent waves with in-kernel lane refill ------------------------------------------------------------
+// Secondary and shadow rays have a heavy-tailed traversal length: with one fixed ray per lane, PMC showed 10-24 % VALU
+// lane utilisation (one long ray keeps 63 finished lanes waiting).  Instead every wave keeps a window of ray indices
+// [wbeg, wend) that it reserves from a per-launch work counter (one atomic per kChunk rays); whenever at least
+// kRefillIdle lanes are idle they are given the next rays of the window — slot = wbeg + rank among idle lanes, from a
+// wave64 ballot + mbcnt prefix sum — and the wave goes back to stepping all lanes together.
+constexpr uint32_t kChunkMax = 512;
+constexpr uint32_t kRefillIdle = 16;
+constexpr uint32_t kNone = 0xffffffffu;
+struct WaveWindow { uint32_t beg, end, chunk; bool more; };
+// Rays per reservation: large enough that the work counter sees one atomic per several hundred rays, small enough that
+// every wave of the grid gets a few chunks even on the thin late-bounce streams.
+MIRT_DI uint32_t pick_chunk(uint32_t n) {
+	const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+	uint32_t c = n / (waves * 4u);
+	c = (c + 63u) & ~63u;
+	return c < 64u ? 64u : (c > kChunkMax ? kChunkMax : c);
+}
+// Gives the lanes with `want` the next ray indices of the wave's window (slot = beg + rank among wanting lanes, from a
+// wave64 ballot + mbcnt prefix sum), reserving a new chunk from the launch's work counter when the window is empty.
+MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_next) {
+	const unsigned long long m = __ballot(want);
+	const uint32_t n_want = static_cast<uint32_t>(__popcll(m));
+	if (n_want == 0u) return kNone;
+	if (w.beg == w.end && w.more) {
+		uint32_t base = 0;
+		if (lane_id() == 0) base = atomicAdd(work_next, w.chunk);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (base >= n) { w.more = false; w.beg = w.end = 0; }
+		else { w.beg = base; w.end = min(base + w.chunk, n); }
+	}
+	const uint32_t take = min(n_want, w.end - w.beg);
+	uint32_t got = kNone;
+	if (want) { const uint32_t r = mask_rank(m); if (r < take) got = w.beg + r; }
+	w.beg += take;
+	return got;
+}
+
+// Persistent wave loop shared by the closest-hit and the any-hit kernels.
+//   * a lane is RUNNING (ri != kNone, !done), DONE (result waiting to be flushed) or EMPTY;
+//   * each lane also holds one PREFETCHED ray (nri + origin/direction[/tfar] in registers) whose loads were issued at the
+//     previous refill event, so switching to it costs no memory wait;
+//   * a refill event (>= kRefillIdle lanes not running) flushes results, switches idle lanes to their prefetched ray,
+//     hands out new indices and issues the loads for the next prefetch — all as batched, mostly coalesced accesses.
+template <bool ANYHIT, bool COUNT, bool ALL_LDS, class LoadRay, class StoreResult>
+MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
+                              LoadRay load_ray, StoreResult store_result) {
+	WaveWindow w{ 0, 0, pick_chunk(n), true };
+	Trav t;
+	TravSpill spill;
+	uint32_t ri = kNone, nri = kNone;
+	bool done = false, occluded = false;
+	float npx = 0, npy = 0, npz = 0, ndx = 1, ndy = 1, ndz = 1, ntf = 0;
+	for (;;) {
+		// ---- refill event ----
+		if (done) { store_result(ri, t, occluded); done = false; ri = kNone; }
+		if (ri == kNone && nri != kNone) { ri = nri; nri = kNone; occluded = false; trav_begin(t, npx, npy, npz, ndx, ndy, ndz, ntf); }
+		{
+			const uint32_t got = wave_take(nri == kNone, w, n, work_next);
+			if (got != kNone) { nri = got; load_ray(got, npx, npy, npz, ndx, ndy, ndz, ntf); }
+		}
+		const bool work_left = w.more || w.beg != w.end;
+		if (__ballot(ri != kNone) == 0ull) { if (__ballot(nri != kNone) == 0ull && !work_left) break; continue; }
+		const bool can_refill = work_left || __ballot(nri != kNone) != 0ull;
+		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
+		for (;;) {
+			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
+			const unsigned long long running = __ballot(ri != kNone && !done);
+			if (running == 0ull) break;
+			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;
+		}
+	}
 }
 
 // Brute force over all prims (the reference as shipped, BVH.hpp:312 / :365), sphere packets staged
@@ -306,7 +395,7 @@ MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds_generic) {
 	const v4f* recs = reinterpret_cast<const v4f*>(sc.recs);
 	const v4f* sph = reinterpret_cast<const v4f*>(sc.spheres);
 	const uint32_t nq = sc.lds_recs * 4u;
-	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[j] = recs[j];
+	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 3u) * sc.lds_recs + (j >> 2)] = recs[j];   // AoS in HBM -> plane-major in LDS
 	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sph[j];
 	__syncthreads();
 	return TraceLds{ lds, lds + nq, (lds_u32*)(lds + nq + sc.lds_spheres) };
@@ -346,32 +435,33 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // ------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
-                                                               const uint32_t* __restrict__ count_ptr, DevCounters* ctr) {
+                                                               const uint32_t* __restrict__ count_ptr, uint32_t* work_next, DevCounters* ctr) {
 	extern __shared__ float4 lds[];
 	const uint32_t n = *count_ptr;
 	if (n == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, static_cast<unsigned long long>(n));
-	if (blockIdx.x * kTraceBlock >= n) return;                       // whole workgroup idle: skip the staging too
 	uint32_t c_nodes = 0, c_spheres = 0;
-	TraceLds tl{ nullptr, nullptr, nullptr };
-	if (sc.use_bvh) tl = stage_bvh(sc, lds);
-	const bool all_lds = bvh_all_in_lds(sc);
-	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
-		const uint32_t i = base + threadIdx.x;
-		const bool active = i < n;
-		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
-		if (active) { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
-		float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
-		int32_t prim = -1;
-		if (sc.use_bvh) {
-			if (active) {
-				if (all_lds) traverse_bvh<false, COUNT, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
-				else traverse_bvh<false, COUNT, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, prim, c_nodes, c_spheres);
-			}
-		} else {
-			traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
+	if (sc.use_bvh && sc.n_recs != 0) {
+		if (blockIdx.x * 64u >= n) return;                           // more workgroups than minimum-size chunks: skip the staging too
+		const TraceLds tl = stage_bvh(sc, lds);
+		auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
+			px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
+		};
+		auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
+		if (bvh_all_in_lds(sc)) trace_persistent<false, COUNT, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<false, COUNT, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+	} else {
+		if (blockIdx.x * kTraceBlock >= n) return;
+		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+			const uint32_t i = base + threadIdx.x;
+			const bool active = i < n;
+			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
+			if (active) { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
+			float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
+			int32_t prim = -1;
+			if (sc.use_bvh == 0) traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
+			if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
 		}
-		if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
 	}
 	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
 }
@@ -564,42 +654,56 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 // ------------------------------------------------------------------------------------------------
 // SHADOW RAY TRACING + accumulation — Traverse_shadow (BVH.hpp:362-404), Renderer.hpp:304-314
 // ------------------------------------------------------------------------------------------------
+// Traverse_shadow (BVH.hpp:362-404): one occlusion flag per shadow ray.  The radiance adds that depend on it are done by
+// k_shadow_resolve, a plain streaming kernel, so the divergent traversal loop carries no extra memory traffic.
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, FrameParams fp, ShadowBuf sh, StreamBuf out, uint32_t bounce,
-                                                              const uint32_t* __restrict__ shadow_count, float* __restrict__ accum, DevCounters* ctr) {
+__global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, ShadowBuf sh, uint32_t* __restrict__ occ_out, uint32_t bounce,
+                                                              const uint32_t* __restrict__ shadow_count, uint32_t* work_next, DevCounters* ctr) {
 	extern __shared__ float4 lds[];
 	const uint32_t n = shadow_count[bounce];
 	if (n == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(n));
-	if (blockIdx.x * kTraceBlock >= n) return;
-	uint32_t c_nodes = 0, c_spheres = 0, c_term = 0;
-	TraceLds tl{ nullptr, nullptr, nullptr };
-	if (sc.use_bvh) tl = stage_bvh(sc, lds);
-	const bool all_lds = bvh_all_in_lds(sc);
-	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
-		const uint32_t i = base + threadIdx.x;
-		const bool active = i < n;
-		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
-		if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
-		bool occluded = false;
-		int32_t dummy = -1;
-		if (sc.use_bvh) {
-			if (active) occluded = all_lds ? traverse_bvh<true, COUNT, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres)
-			                               : traverse_bvh<true, COUNT, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c_nodes, c_spheres);
-		} else {
-			occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c_spheres);
-		}
-		if (active) {
-			f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
-			if (!occluded) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }     // Renderer.hpp:307-311
-			R.x += sh.er[i]; R.y += sh.eg[i]; R.z += sh.eb[i];                        // Renderer.hpp:339-341 / 348-350
-			const uint32_t dest = sh.dest[i];
-			if (dest & kDestAccum) { c_term++; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
-			else { out.rr[dest] = R.x; out.rg[dest] = R.y; out.rb[dest] = R.z; }
+	uint32_t c_nodes = 0, c_spheres = 0;
+	if (sc.use_bvh && sc.n_recs != 0) {
+		if (blockIdx.x * 64u >= n) return;
+		const TraceLds tl = stage_bvh(sc, lds);
+		auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
+			px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
+		};
+		auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
+		if (bvh_all_in_lds(sc)) trace_persistent<true, COUNT, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<true, COUNT, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+	} else {
+		if (blockIdx.x * kTraceBlock >= n) return;
+		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+			const uint32_t i = base + threadIdx.x;
+			const bool active = i < n;
+			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
+			if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
+			bool occluded = false;
+			int32_t dummy = -1;
+			if (sc.use_bvh == 0) occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c_spheres);
+			if (active) occ_out[i] = occluded ? 1u : 0u;
 		}
 	}
-	wave_sum(c_term, &ctr->terminated);
 	if (COUNT) { wave_sum(c_nodes, &ctr->shadow_nodes); wave_sum(c_spheres, &ctr->shadow_spheres); }
+}
+
+// Shadow accumulation + deferred radiance finalisation: (R + unoccluded NEE) + emissive, the reference's add order
+// (Renderer.hpp:307-311, then 339-341 / 348-350), written to the next stream's radiance slot or added to the accumulator.
+__global__ __launch_bounds__(kBlock) void k_shadow_resolve(FrameParams fp, ShadowBuf sh, const uint32_t* __restrict__ occ, StreamBuf out, uint32_t bounce,
+                                                           const uint32_t* __restrict__ shadow_count, float* __restrict__ accum, DevCounters* ctr) {
+	const uint32_t n = shadow_count[bounce];
+	uint32_t c_term = 0;
+	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+		f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
+		if (occ[i] == 0u) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }
+		R.x += sh.er[i]; R.y += sh.eg[i]; R.z += sh.eb[i];
+		const uint32_t dest = sh.dest[i];
+		if (dest & kDestAccum) { c_term++; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
+		else { out.rr[dest] = R.x; out.rg[dest] = R.y; out.rb[dest] = R.z; }
+	}
+	wave_sum(c_term, &ctr->terminated);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,17 +744,17 @@ __global__ __launch_bounds__(kTraceBlock) void k_debug_shadow(SceneDev sc, const
 	uint32_t c0 = 0, c1 = 0;
 	if (blockIdx.x * kTraceBlock >= n) return;
 	TraceLds tl{ nullptr, nullptr, nullptr };
-	if (sc.use_bvh) tl = stage_bvh(sc, lds);
-	const bool all_lds = bvh_all_in_lds(sc);
+	const bool bvh = sc.use_bvh && sc.n_recs != 0;
+	if (bvh) tl = stage_bvh(sc, lds);
 	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
 		const uint32_t i = base + threadIdx.x;
 		const bool active = i < n;
 		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
 		if (active) { px = p[i]; py = p[n + i]; pz = p[2 * n + i]; dx = d[i]; dy = d[n + i]; dz = d[2 * n + i]; tfar = tfar_in[i]; }
 		bool o = false; int32_t dummy = -1;
-		if (sc.use_bvh) { if (active) o = all_lds ? traverse_bvh<true, false, true>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1)
-		                                            : traverse_bvh<true, false, false>(sc, tl, px, py, pz, dx, dy, dz, tfar, dummy, c0, c1); }
-		else o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
+		if (bvh) {
+			if (active) { Trav t; TravSpill spill; trav_begin(t, px, py, pz, dx, dy, dz, tfar); while (!trav_step<true, false, false>(sc, tl, t, spill, o, c0, c1)) {} }
+		} else if (sc.use_bvh == 0) o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
 		if (active) occ[i] = o ? 1 : 0;
 	}
 }

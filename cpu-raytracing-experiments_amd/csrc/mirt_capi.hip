@@ -74,6 +74,7 @@ struct mirt_ctx {
 	StreamBuf stream_buf[2]{};
 	ShadowBuf shadow_buf{};
 	float* hit_tfar = nullptr;
+	uint32_t* shadow_occ = nullptr;      // one occlusion flag per shadow ray (k_trace_shadow -> k_shadow_resolve)
 	int32_t* hit_prim = nullptr;
 
 	// profiling
@@ -133,10 +134,10 @@ int ensure_streams(mirt_ctx* c) {
 	const uint32_t cap = static_cast<uint32_t>(cap64);
 	const uint32_t nb = c->policy.max_bounces;
 	if (cap == c->capacity && nb == c->arena_bounces && c->arena.ptr) return MIRT_OK;
-	const size_t planes = 2 * 14 + 2 + 17;
+	const size_t planes = 2 * 14 + 2 + 17 + 1;
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	HIP_TRY(c, c->arena.ensure(planes * plane_bytes));
-	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 2 + 2) * sizeof(uint32_t)));
+	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 4 + 4) * sizeof(uint32_t)));
 	char* p = c->arena.as<char>();
 	auto take = [&]() { void* r = p; p += plane_bytes; return r; };
 	for (int b = 0; b < 2; b++) {
@@ -155,6 +156,7 @@ int ensure_streams(mirt_ctx* c) {
 	h.rr = (float*)take(); h.rg = (float*)take(); h.rb = (float*)take();
 	h.er = (float*)take(); h.eg = (float*)take(); h.eb = (float*)take();
 	h.dest = (uint32_t*)take();
+	c->shadow_occ = (uint32_t*)take();
 	c->capacity = cap;
 	c->arena_bounces = nb;
 	return MIRT_OK;
@@ -222,6 +224,8 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	if (total == 0) return MIRT_OK;
 	uint32_t* stream_count = c->counts.as<uint32_t>();
 	uint32_t* shadow_count = stream_count + nb + 1;
+	uint32_t* work_next = shadow_count + nb;            // per-launch work counters of the persistent trace kernels
+	uint32_t* work_next_shadow = work_next + nb;
 	DevCounters* ctr = c->counters.as<DevCounters>();
 	float* accum = c->accumulator.as<float>();
 	SceneDev sc = c->scene;
@@ -232,22 +236,23 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
 	const uint32_t tlds = trace_lds(c);
 
-	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 2 + 2) * sizeof(uint32_t), c->stream));
+	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 4) * sizeof(uint32_t), c->stream));
 	{ Bracket t(c, MIRT_K_RAYGEN);
 	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], stream_count); }
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
 		const StreamBuf& in = c->stream_buf[bounce & 1u];
 		const StreamBuf& out = c->stream_buf[(bounce & 1u) ^ 1u];
 		{ Bracket t(c, MIRT_K_TRACE);
-		  if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr);
-		  else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, ctr); }
+		  if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce, ctr);
+		  else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce, ctr); }
 		{ Bracket t(c, MIRT_K_SHADE);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
 		if (fp.mis && bounce + 1 < nb) {
 			Bracket t(c, MIRT_K_SHADOW);
-			if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, fp, c->shadow_buf, out, bounce, shadow_count, accum, ctr);
-			else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, fp, c->shadow_buf, out, bounce, shadow_count, accum, ctr);
+			if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, c->shadow_buf, c->shadow_occ, bounce, shadow_count, work_next_shadow + bounce, ctr);
+			else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, c->shadow_buf, c->shadow_occ, bounce, shadow_count, work_next_shadow + bounce, ctr);
+			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->shadow_buf, c->shadow_occ, out, bounce, shadow_count, accum, ctr);
 		}
 	}
 	HIP_TRY(c, hipGetLastError());
@@ -570,7 +575,8 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	DeviceBuffer rays, res, cnt;
-	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(4));
+	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(8));
+	HIP_TRY(c, hipMemset(cnt.ptr, 0, 8));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
@@ -582,7 +588,7 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	DevCounters* scratch_ctr = nullptr;
 	DeviceBuffer ctr; HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
-	hipLaunchKernelGGL(k_trace_closest<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), scratch_ctr);
+	hipLaunchKernelGGL(k_trace_closest<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Per-dispatch view of two rocprofv3 --pmc passes (p1: SQ_WAVES.. p2: LDS/VMEM..): lane utilisation, wait share, LDS conflicts."""
+import collections, csv, glob, sys
+root = sys.argv[1]
+def load(f):
+    rows = collections.defaultdict(dict)
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "mirt" not in k: continue
+        d = rows[(int(row["Dispatch_Id"]), k)]
+        d[row["Counter_Name"]] = float(row["Counter_Value"]); d["us"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+    return rows
+r1 = load(glob.glob(f"{root}/p1/*/*_counter_collection.csv")[0]); r2 = load(glob.glob(f"{root}/p2/*/*_counter_collection.csv")[0])
+pat = sys.argv[2] if len(sys.argv) > 2 else "trace"
+for (i, k), d in sorted(r1.items()):
+    if pat not in k: continue
+    e = r2.get((i, k), {})
+    util = d["SQ_THREAD_CYCLES_VALU"] / max(d["SQ_ACTIVE_INST_VALU"] * 64, 1)
+    print(i, k[:26].ljust(26), "us %7.1f" % d["us"], "VALU %.3g SALU %.3g LDS %.3g VMEM %.3g" % (d["SQ_INSTS_VALU"], d["SQ_INSTS_SALU"], e.get("SQ_INSTS_LDS", 0), e.get("SQ_INSTS_VMEM", 0)),
+          "lane-util %.2f" % util, "wait %.2f" % (d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]), "lds-conflict %.2f" % (e.get("SQ_LDS_BANK_CONFLICT", 0) / max(e.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
