@@ -97,6 +97,8 @@ def load_library():
         "mirt_debug_trace_closest": [P, C.c_size_t, vp, vp, vp, vp],
         "mirt_debug_trace_shadow": [P, C.c_size_t, vp, vp, vp, vp],
         "mirt_debug_math": [P, i32, C.c_size_t, vp, vp],
+        "mirt_debug_info": [P, vp],
+        "mirt_debug_allow_half_boxes": [P, i32],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
@@ -148,7 +150,8 @@ class Renderer:
     """
 
     def __init__(self, scene: Scene, device: int = 0, max_bounces: int = 16, buckets: int = 5, mis: bool = True,
-                 use_bvh: bool = False, count_traffic: bool = False, profile: bool = False, max_batch: int = 0):
+                 use_bvh: bool = False, count_traffic: bool = False, profile: bool = False, max_batch: int = 0,
+                 allow_half_boxes: bool = True):
         self._lib = load_library()
         self._ctx = C.c_void_p()
         rc = self._lib.mirt_create(device, C.byref(self._ctx))
@@ -159,6 +162,7 @@ class Renderer:
         self.framebuffer = None
         self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), int(profile), max_batch, 0)
         self._check(self._lib.mirt_set_policy(self._ctx, C.byref(self.policy)))
+        self._check(self._lib.mirt_debug_allow_half_boxes(self._ctx, int(allow_half_boxes)))
         self.UpdateScene()
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -271,6 +275,12 @@ class Renderer:
         t = KernelTimes()
         self._check(self._lib.mirt_get_kernel_times(self._ctx, C.byref(t), int(reset)))
         return {k: {"ms": t.ms[i], "launches": int(t.launches[i])} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def debug_info(self) -> dict:
+        out = (C.c_uint32 * 8)()
+        self._check(self._lib.mirt_debug_info(self._ctx, out))
+        keys = ("records", "lds_records", "lds_spheres", "depth", "half_boxes", "trace_lds_bytes", "trace_workgroups_per_cu", "cus")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def stream_handle(self) -> int:
         p = C.c_void_p()

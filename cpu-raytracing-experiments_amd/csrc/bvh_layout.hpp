@@ -12,6 +12,12 @@
 // One 64-B fetch therefore serves both of a node's children (the reference stores them adjacently at
 // first_id, first_id+1 for the same reason).
 //
+// Half-precision variant (32 B per record, used when it is precise enough for the scene): the same twelve planes as
+// IEEE binary16, lo planes rounded toward -inf and hi planes toward +inf so the boxes only ever grow:
+//     words 0..5 = (lo0|lo1<<16, hi0|hi1<<16) for x, y, z;  words 6,7 = child references.
+// Halving the record halves the LDS bytes and read instructions per traversal step and lets two 16-wave workgroups
+// share a CU's LDS.  The slab arithmetic itself stays f32.
+//
 // Boxes are CONSERVATIVE: each leaf box is its spheres' bbox grown by pad_rel*(max|centre|+radius) and
 // rounded outward, inner boxes are unions.  The growth absorbs the rounding of the slab test and of the
 // reference's sphere test (BVH.hpp:251-267), so the traversal never culls a sphere the reference's
@@ -34,9 +40,102 @@ constexpr float kPadRel = 0x1p-18f;
 
 struct PadBox { float lo[3], hi[3]; };
 
+// ---- IEEE binary16 with directed rounding (host side; the device decodes with v_cvt_f32_f16) -------------------------
+inline float half_to_float(uint16_t h) {
+	const uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+	uint32_t bits;
+	if (exp == 0) {
+		if (man == 0) bits = sign;
+		else { int e = -1; uint32_t m = man; do { e++; m <<= 1; } while (!(m & 0x400u)); bits = sign | ((127 - 15 - e) << 23) | ((m & 0x3ffu) << 13); }
+	} else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+	else bits = sign | ((exp - 15 + 127) << 23) | (man << 13);
+	float f; std::memcpy(&f, &bits, 4); return f;
+}
+inline uint16_t half_next_up(uint16_t h) {                 // smallest half greater than h (h finite or -inf)
+	if ((h & 0x7fffu) == 0) return 0x0001u;                // +-0 -> smallest positive subnormal
+	return (h & 0x8000u) ? static_cast<uint16_t>(h - 1) : static_cast<uint16_t>(h + 1);
+}
+inline uint16_t half_next_down(uint16_t h) {
+	if ((h & 0x7fffu) == 0) return 0x8001u;
+	return (h & 0x8000u) ? static_cast<uint16_t>(h + 1) : static_cast<uint16_t>(h - 1);
+}
+inline uint16_t float_to_half_nearest(float f) {           // round-to-nearest-even, overflow -> inf
+	uint32_t x; std::memcpy(&x, &f, 4);
+	const uint32_t sign = (x >> 16) & 0x8000u;
+	x &= 0x7fffffffu;
+	if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0u));
+	if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);                   // >= 65520 rounds to inf
+	if (x < 0x33000001u) return static_cast<uint16_t>(sign);                               // < 2^-25 rounds to 0
+	const int e = static_cast<int>(x >> 23) - 127;
+	uint32_t man = (x & 0x7fffffu) | 0x800000u;
+	int shift = (e < -14) ? (13 + (-14 - e)) : 13;
+	uint32_t h = man >> shift;
+	const uint32_t rem = man & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+	if (rem > halfway || (rem == halfway && (h & 1u))) h++;
+	if (e < -14) return static_cast<uint16_t>(sign | h);                                   // subnormal (carry into exp 1 is correct)
+	h = (h & 0x3ffu) + ((h & 0x400u) ? 0u : 0u) + (static_cast<uint32_t>(e + 15) << 10) + ((h >> 11) << 10);   // h has the implicit 1 at bit 10; a carry-out bumps the exponent
+	return static_cast<uint16_t>(sign | h);
+}
+inline uint16_t float_to_half_down(float f) {              // largest half <= f
+	uint16_t h = float_to_half_nearest(f);
+	if (half_to_float(h) > f) h = half_next_down(h);
+	return h;
+}
+inline uint16_t float_to_half_up(float f) {                // smallest half >= f
+	uint16_t h = float_to_half_nearest(f);
+	if (half_to_float(h) < f) h = half_next_up(h);
+	return h;
+}
+inline float half_ulp_at(float magnitude) {                // spacing of binary16 values around |magnitude|
+	if (magnitude < 6.103515625e-05f) return 5.9604644775390625e-08f;
+	int e; std::frexp(magnitude, &e);                       // magnitude = m * 2^e, m in [0.5, 1)
+	return std::ldexp(1.0f, e - 11);
+}
+
 inline uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 24) | first; }
 
 // Returns "" on success, otherwise the reason the tree cannot be laid out.
+// 32-B half-precision records from the 64-B ones.  Returns false (and leaves `out` empty) when binary16 is not adequate:
+// a coordinate beyond +-60000, more than 65535 records (the u16 traversal stack), or a leaf box whose smallest extent is
+// under 8 quantisation steps (the box would grow by more than ~25 %).
+inline bool build_half_records(const std::vector<float>& recs, std::vector<uint32_t>& out) {
+	out.clear();
+	const size_t n = recs.size() / 16;
+	if (n == 0 || n > 65535) return false;
+	for (size_t r = 0; r < n; r++) {
+		const float* q = recs.data() + r * 16;
+		for (int child = 0; child < 2; child++) {
+			uint32_t ref; std::memcpy(&ref, &q[12 + child], 4);
+			float amax = 0.0f, min_extent = INFINITY;
+			for (int a = 0; a < 3; a++) {
+				const float lo = q[a * 4 + child], hi = q[a * 4 + 2 + child];
+				if (lo == FLT_MAX && hi == FLT_MAX) { min_extent = INFINITY; amax = 0.0f; break; }     // the empty child of a single-leaf tree
+				amax = std::fmax(amax, std::fmax(std::fabs(lo), std::fabs(hi)));
+				min_extent = std::fmin(min_extent, hi - lo);
+			}
+			if (amax > 60000.0f) return false;
+			if ((ref & kLeafBit) && min_extent < 8.0f * half_ulp_at(amax)) return false;
+		}
+	}
+	out.resize(n * 8);
+	for (size_t r = 0; r < n; r++) {
+		const float* q = recs.data() + r * 16;
+		uint32_t* w = out.data() + r * 8;
+		for (int a = 0; a < 3; a++) {
+			uint16_t lo[2], hi[2];
+			for (int child = 0; child < 2; child++) {
+				const float l = q[a * 4 + child], h = q[a * 4 + 2 + child];
+				if (l == FLT_MAX && h == FLT_MAX) { lo[child] = hi[child] = 0x7c00u; continue; }       // +inf box: every slab test misses
+				lo[child] = float_to_half_down(l); hi[child] = float_to_half_up(h);
+			}
+			w[a * 2] = lo[0] | (static_cast<uint32_t>(lo[1]) << 16);
+			w[a * 2 + 1] = hi[0] | (static_cast<uint32_t>(hi[1]) << 16);
+		}
+		std::memcpy(&w[6], &q[12], 8);
+	}
+	return true;
+}
+
 inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, const mirt_sphere* prims, uint32_t n_prims,
                                  std::vector<float>& recs /* 16 floats per record */, uint32_t* max_depth_out) {
 	recs.clear();

@@ -46,6 +46,7 @@ struct SceneDev {
 	uint32_t n_spheres, n_recs, n_mat, n_lights;
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
+	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each) and the LDS stack holds u16 entries
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
 	float hdri_fw, hdri_fh;
@@ -212,7 +213,10 @@ MIRT_DI void sphere_closest_tie(float4 s, int32_t prim, float px, float py, floa
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] words
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] entries (u32, or u16 with half records)
+MIRT_DI float half_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(w & 0xffffu))); }
+MIRT_DI float half_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(w >> 16))); }
 MIRT_DI float4 to_float4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 // One lane's traversal state.  A lane keeps it in registers across refills of OTHER lanes (persistent waves below).
@@ -234,50 +238,78 @@ MIRT_DI void trav_begin(Trav& t, float px, float py, float pz, float dx, float d
 // One step = one 64-B record: slab-test both children against the current tfar, intersect hit leaf children at once,
 // re-check inner children against the shrunken tfar, enter the nearer, push the other (or pop).  Returns true when this
 // ray is finished (stack empty, or ANYHIT occluder found -> occluded = true).
-template <bool ANYHIT, bool COUNT, bool ALL_LDS>
+template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF>
 MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres) {
 	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
-	// are consecutive words, conflict-free); deeper entries (rare) use a scratch array.
-	lds_u32* const lstack = lds.stack + threadIdx.x;
+	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
 	const uint32_t lstride = blockDim.x;
 	const uint32_t cur = t.cur;
-	v4f q0, q1, q2, q3;
-	if (ALL_LDS || cur < sc.lds_recs) {     // staged records are stored plane-major (q0[], q1[], q2[], q3[]): 16-B stride between lanes' addresses
-		const lds_v4f* r = lds.recs + cur; const uint32_t ns = sc.lds_recs;
-		q0 = r[0]; q1 = r[ns]; q2 = r[2u * ns]; q3 = r[3u * ns];
+	// child boxes: (lo, hi) per axis for child 0 (a) and child 1 (b)
+	float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
+	uint32_t c0, c1;
+	if (HALF) {
+		v4f q0, q1;                           // 32-B record: 12 binary16 planes + 2 child references
+		if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
+		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 2ull * cur; q0 = r[0]; q1 = r[1]; }
+		const uint32_t w0 = __float_as_uint(q0.x), w1 = __float_as_uint(q0.y), w2 = __float_as_uint(q0.z), w3 = __float_as_uint(q0.w);
+		const uint32_t w4 = __float_as_uint(q1.x), w5 = __float_as_uint(q1.y);
+		ax0 = half_lo(w0); bx0 = half_hi(w0); ax1 = half_lo(w1); bx1 = half_hi(w1);
+		ay0 = half_lo(w2); by0 = half_hi(w2); ay1 = half_lo(w3); by1 = half_hi(w3);
+		az0 = half_lo(w4); bz0 = half_hi(w4); az1 = half_lo(w5); bz1 = half_hi(w5);
+		c0 = __float_as_uint(q1.z); c1 = __float_as_uint(q1.w);
+	} else {
+		v4f q0, q1, q2, q3;
+		if (ALL_LDS || cur < sc.lds_recs) {     // staged records are stored plane-major (q0[], q1[], q2[], q3[]): 16-B stride between lanes' addresses
+			const lds_v4f* r = lds.recs + cur; const uint32_t ns = sc.lds_recs;
+			q0 = r[0]; q1 = r[ns]; q2 = r[2u * ns]; q3 = r[3u * ns];
+		}
+		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+		ax0 = q0.x; bx0 = q0.y; ax1 = q0.z; bx1 = q0.w;
+		ay0 = q1.x; by0 = q1.y; ay1 = q1.z; by1 = q1.w;
+		az0 = q2.x; bz0 = q2.y; az1 = q2.z; bz1 = q2.w;
+		c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
 	}
-	else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 4ull * cur; q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
 	if (COUNT) n_nodes += 2;
 	const RaySlab& rs = t.rs;
 	float ta, tb;
-	bool ha = slab_hit(__builtin_fmaf(q0.x, rs.ix, rs.nx), __builtin_fmaf(q0.z, rs.ix, rs.nx),
-	                   __builtin_fmaf(q1.x, rs.iy, rs.ny), __builtin_fmaf(q1.z, rs.iy, rs.ny),
-	                   __builtin_fmaf(q2.x, rs.iz, rs.nz), __builtin_fmaf(q2.z, rs.iz, rs.nz), t.tfar, ta);
-	bool hb = slab_hit(__builtin_fmaf(q0.y, rs.ix, rs.nx), __builtin_fmaf(q0.w, rs.ix, rs.nx),
-	                   __builtin_fmaf(q1.y, rs.iy, rs.ny), __builtin_fmaf(q1.w, rs.iy, rs.ny),
-	                   __builtin_fmaf(q2.y, rs.iz, rs.nz), __builtin_fmaf(q2.w, rs.iz, rs.nz), t.tfar, tb);
-	const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-#pragma unroll
-	for (int k = 0; k < 2; k++) {
-		const uint32_t c = k ? c1 : c0;
-		const bool h = k ? hb : ha;
-		if (h && (c & kLeafBit)) {
-			const uint32_t first = c & 0xffffffu, count = ((c >> 24) & 0x7fu) + 1u;
-			for (uint32_t p = first; p < first + count; p++) {
-				if (COUNT) n_spheres++;
-				float4 s;
-				if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
-				if (ANYHIT) { if (sphere_occludes(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar)) { occluded = true; return true; } }
-				else sphere_closest_tie(s, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
+	bool ha = slab_hit(__builtin_fmaf(ax0, rs.ix, rs.nx), __builtin_fmaf(ax1, rs.ix, rs.nx),
+	                   __builtin_fmaf(ay0, rs.iy, rs.ny), __builtin_fmaf(ay1, rs.iy, rs.ny),
+	                   __builtin_fmaf(az0, rs.iz, rs.nz), __builtin_fmaf(az1, rs.iz, rs.nz), t.tfar, ta);
+	bool hb = slab_hit(__builtin_fmaf(bx0, rs.ix, rs.nx), __builtin_fmaf(bx1, rs.ix, rs.nx),
+	                   __builtin_fmaf(by0, rs.iy, rs.ny), __builtin_fmaf(by1, rs.iy, rs.ny),
+	                   __builtin_fmaf(bz0, rs.iz, rs.nz), __builtin_fmaf(bz1, rs.iz, rs.nz), t.tfar, tb);
+	// Hit leaf children are intersected at once, child 0 before child 1.  ONE instance of the sphere code serves both:
+	// each lane queues its first hit leaf in l0 (and, rarely, a second one in l1) and the wave loops while any lane has
+	// one queued — an unrolled copy per child ran ~90 sphere-test instructions on almost every step for ~5 % of the lanes.
+	{
+		const bool la = ha && (c0 & kLeafBit), lb = hb && (c1 & kLeafBit);
+		uint32_t l0 = la ? c0 : (lb ? c1 : 0u);
+		uint32_t l1 = (la && lb) ? c1 : 0u;
+		while (__ballot(l0 != 0u) != 0ull) {
+			if (l0 != 0u) {
+				const uint32_t first = l0 & 0xffffffu, count = ((l0 >> 24) & 0x7fu) + 1u;
+				for (uint32_t p = first; p < first + count; p++) {
+					if (COUNT) n_spheres++;
+					float4 s;
+					if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
+					if (ANYHIT) { if (sphere_occludes(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar)) { occluded = true; break; } }
+					else sphere_closest_tie(s, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
+				}
 			}
+			l0 = (ANYHIT && occluded) ? 0u : l1;
+			l1 = 0u;
 		}
+		if (ANYHIT && occluded) return true;
 	}
 	ha = ha && !(c0 & kLeafBit); hb = hb && !(c1 & kLeafBit);
 	if (!ANYHIT) { ha = ha && ta <= t.tfar; hb = hb && tb <= t.tfar; }          // re-check against the shrunken tfar
 	if (ha && hb) {
 		const bool a_first = ANYHIT ? true : (ta <= tb);
-		const uint32_t far = a_first ? c1 : c0;                                // depth < 64 is validated on the host
-		if (t.sp < kLdsStack) lstack[t.sp * lstride] = far; else if (t.sp < kStack) spill.e[t.sp - kLdsStack] = far;
+		const uint32_t far = a_first ? c1 : c0;                                // inner reference = record index; depth < 64 is validated on the host
+		if (t.sp < kLdsStack) {
+			if (HALF) ((lds_u16*)lds.stack)[t.sp * lstride + threadIdx.x] = static_cast<uint16_t>(far);
+			else lds.stack[t.sp * lstride + threadIdx.x] = far;
+		} else if (t.sp < kStack) spill.e[t.sp - kLdsStack] = far;
 		t.sp++;
 		t.cur = a_first ? c0 : c1;
 		return false;
@@ -286,7 +318,10 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	if (hb) { t.cur = c1; return false; }
 	if (t.sp == 0) return true;
 	--t.sp;
-	if (t.sp < kLdsStack) t.cur = lstack[t.sp * lstride]; else t.cur = spill.e[t.sp - kLdsStack];
+	if (t.sp < kLdsStack) {
+		if (HALF) t.cur = ((lds_u16*)lds.stack)[t.sp * lstride + threadIdx.x];
+		else t.cur = lds.stack[t.sp * lstride + threadIdx.x];
+	} else t.cur = spill.e[t.sp - kLdsStack];
 	return false;
 }
 
@@ -334,7 +369,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_
 //     previous refill event, so switching to it costs no memory wait;
 //   * a refill event (>= kRefillIdle lanes not running) flushes results, switches idle lanes to their prefetched ray,
 //     hands out new indices and issues the loads for the next prefetch — all as batched, mostly coalesced accesses.
-template <bool ANYHIT, bool COUNT, bool ALL_LDS, class LoadRay, class StoreResult>
+template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
 	WaveWindow w{ 0, 0, pick_chunk(n), true };
@@ -356,7 +391,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n,
 		const bool can_refill = work_left || __ballot(nri != kNone) != 0ull;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
 		for (;;) {
-			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
+			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS, HALF>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
 			const unsigned long long running = __ballot(ri != kNone && !done);
 			if (running == 0ull) break;
 			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;
@@ -394,8 +429,10 @@ MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds_generic) {
 	lds_v4f* lds = (lds_v4f*)lds_generic;
 	const v4f* recs = reinterpret_cast<const v4f*>(sc.recs);
 	const v4f* sph = reinterpret_cast<const v4f*>(sc.spheres);
-	const uint32_t nq = sc.lds_recs * 4u;
-	for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 3u) * sc.lds_recs + (j >> 2)] = recs[j];   // AoS in HBM -> plane-major in LDS
+	const uint32_t planes = sc.half_boxes ? 2u : 4u;                 // float4 per record
+	const uint32_t nq = sc.lds_recs * planes;
+	if (sc.half_boxes) { for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 1u) * sc.lds_recs + (j >> 1)] = recs[j]; }
+	else { for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 3u) * sc.lds_recs + (j >> 2)] = recs[j]; }   // AoS in HBM -> plane-major in LDS
 	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sph[j];
 	__syncthreads();
 	return TraceLds{ lds, lds + nq, (lds_u32*)(lds + nq + sc.lds_spheres) };
@@ -448,8 +485,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, Stre
 			px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
 		};
 		auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
-		if (bvh_all_in_lds(sc)) trace_persistent<false, COUNT, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<false, COUNT, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		const bool all = bvh_all_in_lds(sc);
+		if (sc.half_boxes) {
+			if (all) trace_persistent<false, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+			else trace_persistent<false, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		} else {
+			if (all) trace_persistent<false, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+			else trace_persistent<false, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		}
 	} else {
 		if (blockIdx.x * kTraceBlock >= n) return;
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
@@ -671,8 +714,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, Shado
 			px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 		};
 		auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
-		if (bvh_all_in_lds(sc)) trace_persistent<true, COUNT, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<true, COUNT, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		const bool all = bvh_all_in_lds(sc);
+		if (sc.half_boxes) {
+			if (all) trace_persistent<true, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+			else trace_persistent<true, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		} else {
+			if (all) trace_persistent<true, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+			else trace_persistent<true, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		}
 	} else {
 		if (blockIdx.x * kTraceBlock >= n) return;
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
@@ -753,7 +802,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_debug_shadow(SceneDev sc, const
 		if (active) { px = p[i]; py = p[n + i]; pz = p[2 * n + i]; dx = d[i]; dy = d[n + i]; dz = d[2 * n + i]; tfar = tfar_in[i]; }
 		bool o = false; int32_t dummy = -1;
 		if (bvh) {
-			if (active) { Trav t; TravSpill spill; trav_begin(t, px, py, pz, dx, dy, dz, tfar); while (!trav_step<true, false, false>(sc, tl, t, spill, o, c0, c1)) {} }
+			if (active) {
+				Trav t; TravSpill spill; trav_begin(t, px, py, pz, dx, dy, dz, tfar);
+				if (sc.half_boxes) { while (!trav_step<true, false, false, true>(sc, tl, t, spill, o, c0, c1)) {} }
+				else { while (!trav_step<true, false, false, false>(sc, tl, t, spill, o, c0, c1)) {} }
+			}
 		} else if (sc.use_bvh == 0) o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
 		if (active) occ[i] = o ? 1 : 0;
 	}

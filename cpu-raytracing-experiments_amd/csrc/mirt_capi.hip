@@ -62,6 +62,7 @@ struct mirt_ctx {
 	CameraParams camera{};
 	uint32_t trace_lds_bytes = 0;    // dynamic LDS of the BVH trace kernels (staged records + spheres)
 	uint32_t bvh_depth = 0;
+	bool allow_half = true;           // binary16 records when adequate (mirt_debug_set(ctx, "half_boxes", 0) forces f32)
 
 	// frame state
 	DeviceBuffer accumulator;        // [local tile][bucket][3][256] f32
@@ -110,9 +111,12 @@ uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
 // Trace kernels are launched as a resident grid (as many 512-thread workgroups as their LDS footprint lets a
 // CU hold) and grid-stride over the stream, so each workgroup stages the BVH into LDS once per launch.
 constexpr uint32_t kLdsPerCu = 160u * 1024u;
-constexpr uint32_t kLdsStackBytes = kLdsStack * kTraceBlock * 4u;   // 64 KB: 16 stack entries for each of 1024 lanes
-constexpr uint32_t kLdsStageBudget = 96u * 1024u;      // staged BVH bytes; + the stack = one 16-wave workgroup per CU
-uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? c->trace_lds_bytes + kLdsStackBytes : kBruteChunk * 16u; }
+// LDS plan of a trace workgroup (1024 lanes): staged BVH bytes + a 16-entry stack per lane.  With binary16 records the
+// stack entries are u16 (32 KB) and the staged bytes are capped at 48 KB so that TWO workgroups (32 waves) share a CU;
+// with f32 records it is a u32 stack (64 KB) + up to 96 KB, one workgroup per CU.
+uint32_t stack_bytes(const mirt_ctx* c) { return kLdsStack * kTraceBlock * (c->scene.half_boxes ? 2u : 4u); }
+uint32_t stage_budget(bool half) { return half ? 48u * 1024u : 96u * 1024u; }
+uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? c->trace_lds_bytes + stack_bytes(c) : kBruteChunk * 16u; }
 uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 	uint32_t per_cu = kLdsPerCu / trace_lds(c);
 	if (per_cu > 2) per_cu = 2;                                       // 2 x 1024 threads = 32 waves, the CU's limit
@@ -361,9 +365,11 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	{ const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
 	  if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str()); }
 	const uint32_t n_recs = static_cast<uint32_t>(recs.size() / 16);
+	std::vector<uint32_t> half_recs;
+	const bool half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
 
 	int r;
-	if ((r = upload(c, c->recs, recs)) || (r = upload(c, c->spheres, sph)) || (r = upload(c, c->prim_mat, pm)) ||
+	if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs)) || (r = upload(c, c->spheres, sph)) || (r = upload(c, c->prim_mat, pm)) ||
 	    (r = upload(c, c->geom, geo)) || (r = upload(c, c->geom_mat, gm)) || (r = upload(c, c->mat_albedo, alb)) ||
 	    (r = upload(c, c->mat_emission, emi)) || (r = upload(c, c->lights, li)) || (r = upload(c, c->hdri, sky))) return r;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -377,9 +383,11 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	c->bvh_depth = depth;
 	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
-	if (static_cast<uint64_t>(n_recs) * 64u + static_cast<uint64_t>(n_spheres) * 16u <= kLdsStageBudget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
-	else { s.lds_recs = std::min<uint32_t>(n_recs, kLdsStageBudget / 64u); s.lds_spheres = 0; }
-	c->trace_lds_bytes = s.lds_recs * 64u + s.lds_spheres * 16u;
+	s.half_boxes = half ? 1u : 0u;
+	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half);
+	if (static_cast<uint64_t>(n_recs) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u <= budget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
+	else { s.lds_recs = std::min<uint32_t>(n_recs, budget / rec_bytes); s.lds_spheres = 0; }
+	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
 	{
 		const int lds_max = static_cast<int>(kLdsPerCu);
 		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_closest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -635,5 +643,16 @@ int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) 
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_math: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }
+
+int mirt_debug_info(mirt_ctx* c, uint32_t out[8]) {
+	if (!c || !out) return MIRT_ERR_ARG;
+	const SceneDev& s = c->scene;
+	uint32_t per_cu = kLdsPerCu / std::max<uint32_t>(trace_lds(c), 1u);
+	per_cu = std::min<uint32_t>(std::max<uint32_t>(per_cu, 1u), 2u);
+	out[0] = s.n_recs; out[1] = s.lds_recs; out[2] = s.lds_spheres; out[3] = c->bvh_depth; out[4] = s.half_boxes;
+	out[5] = trace_lds(c); out[6] = per_cu; out[7] = static_cast<uint32_t>(c->n_cu);
+	return MIRT_OK;
+}
+int mirt_debug_allow_half_boxes(mirt_ctx* c, int allow) { if (!c) return MIRT_ERR_ARG; c->allow_half = allow != 0; return MIRT_OK; }
 
 } // extern "C"

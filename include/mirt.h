@@ -185,6 +185,12 @@ int mirt_debug_trace_shadow(mirt_ctx* ctx, size_t n, const float* p_xyz, const f
  *     7 rng: hash_2d(x,y) then 3 pcg draws as float + bounded int  [Random.hpp:5-50]  in: x[n],y[n],range[n] as u32 bits  out: 5n (hash bits, f0,f1,f2, bounded bits)
  */
 int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out);
+/* Introspection of the GPU-internal BVH layout (tests, bench, DESIGN.md numbers):
+ * out[0] records, out[1] records staged in LDS, out[2] spheres staged in LDS, out[3] tree depth, out[4] 1 if the 32-B
+ * binary16 records are in use, out[5] dynamic LDS bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
+int mirt_debug_info(mirt_ctx* ctx, uint32_t out[8]);
+/* Test knob: forbid (0) / allow (1, default) the binary16 records; takes effect at the next mirt_set_scene. */
+int mirt_debug_allow_half_boxes(mirt_ctx* ctx, int allow);
 
 #ifdef __cplusplus
 }

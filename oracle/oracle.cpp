@@ -670,6 +670,14 @@ static void bvh_pad(BVH& bvh, float pad_rel) {
 		bvh.padded[k] = b;
 	}
 }
+// Optional: round every padded box outward to IEEE binary16 (lo toward -inf, hi toward +inf), as the product's 32-B
+// half-precision records do (csrc/bvh_layout.hpp build_half_records); the values the slab test sees are then identical.
+static void bvh_quantize_half(BVH& bvh) {
+	for (Box& b : bvh.padded) for (int a = 0; a < 3; a++) {
+		b.mn[a] = _cvtsh_ss(_cvtss_sh(b.mn[a], _MM_FROUND_TO_NEG_INF | _MM_FROUND_NO_EXC));
+		b.mx[a] = _cvtsh_ss(_cvtss_sh(b.mx[a], _MM_FROUND_TO_POS_INF | _MM_FROUND_NO_EXC));
+	}
+}
 struct RaySlab { float ix, iy, iz, nx, ny, nz; };
 static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
 	RaySlab s;      // zero / denormal-small components get a huge finite reciprocal (see make_slab in csrc/kernels.hpp)
@@ -1121,6 +1129,7 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	return 0;
 }
 void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.bvh, pad_rel); }
+void orc_set_half_boxes(void* h, int half) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.bvh, o.bvh.pad_rel); if (half) bvh_quantize_half(o.bvh); }
 int orc_node_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->bvh.nodes.size()); }
 int orc_light_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->lights.size()); }
 void orc_get_bvh(void* h, void* nodes, void* prims) {

@@ -34,6 +34,7 @@ def load():
     lib.orc_create.restype = vp
     lib.orc_destroy.argtypes = [vp]
     lib.orc_set_scene.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32]
+    lib.orc_set_half_boxes.argtypes = [vp, i32]
     lib.orc_node_count.argtypes = [vp]
     lib.orc_light_count.argtypes = [vp]
     lib.orc_get_bvh.argtypes = [vp, vp, vp]
@@ -115,6 +116,10 @@ class Oracle:
         pos = np.ascontiguousarray(cam.pos, dtype=np.float32)
         ori = np.ascontiguousarray(cam.orient, dtype=np.float32)
         self.lib.orc_set_camera(self.h, _p(pos), _p(ori), float(cam.half_width), float(cam.half_height), float(cam.z), float(cam.exposure))
+
+    def set_half_boxes(self, half):
+        """Mode 2 only: quantise the padded boxes to binary16 like the product's 32-B records (call after update_scene)."""
+        self.lib.orc_set_half_boxes(self.h, int(bool(half)))
 
     def bvh(self):
         n = self.lib.orc_node_count(self.h)

@@ -185,9 +185,24 @@ def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
     assert cg["rays"] == co["rays"] and cg["terminated"] == co["terminated"]
     if scene_name != "S8a":
         # same traversal algorithm as the oracle's mode 2 -> same visit counts (feeds the roofline's algorithmic bytes)
-        t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.Resize(w, h); t.Accumulate(spp)
+        t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.set_half_boxes(r.debug_info()["half_boxes"]); t.Resize(w, h); t.Accumulate(spp)
         ct = t.counters()
         assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
+    r.close()
+
+
+@pytest.mark.parametrize("allow_half", [True, False])
+def test_record_formats_agree(mirt, allow_half):
+    """binary16 (32-B) and f32 (64-B) BVH records are both only conservative culling structures: same accumulators."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(128, 128); o.Accumulate(5)
+    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, count_traffic=True); r.Resize(128, 128); r.Accumulate(5)
+    info = r.debug_info()
+    assert info["half_boxes"] == int(allow_half) and info["records"] == 999 and info["lds_records"] == 999 and info["lds_spheres"] == 1000
+    assert info["trace_workgroups_per_cu"] == (2 if allow_half else 1)
+    assert_same(r.accumulator(), o.accumulator(), f"accumulator (half={allow_half})")
+    t = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH); t.set_half_boxes(allow_half); t.Resize(128, 128); t.Accumulate(5)
+    assert r.counters()["nodes"] == t.counters()["nodes"] and r.counters()["spheres"] == t.counters()["spheres"]
     r.close()
 
 
