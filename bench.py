@@ -28,9 +28,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s 
 
 
 def algorithmic_bytes(c):
-    """per closest-hit ray 24 B (p,dir) + 12 B (tfar,primID,matID) + 32 B per BVH node box-tested
-    + 32 B per sphere tested."""
-    return 36 * c["rays"] + 32 * (c["nodes"] + c["spheres"])
+    """SURVEY.md §8d, for the k_trace launches (closest-hit rays of bounce b + shadow rays of bounce b-1 in one kernel):
+    per closest-hit ray 24 B (p,dir) + 12 B (tfar,primID,matID) + 32 B per BVH child box tested + 32 B per sphere tested;
+    per shadow ray 28 B (p,dir,tfar) + 1/8 B (occluded bit) + 32 B per box + 32 B per sphere."""
+    return (36 * c["rays"] + 32 * (c["nodes"] + c["spheres"])
+            + 28.125 * c["shadow_rays"] + 32 * (c["shadow_nodes"] + c["shadow_spheres"]))
 
 
 def shape_for(n_gpus, base=1024):
@@ -175,13 +177,14 @@ def main():
         tr = ktimes["trace"]
         if tr["launches"]:
             avg_ms = tr["ms"] / tr["launches"]
-            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+            roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
                         "traffic": None, "launches": tr["launches"], "avg_launch_ms": avg_ms}
             if counts:
                 ab = algorithmic_bytes(counts)
                 ach = ab / (tr["ms"] * 1e-3) / 1e9
                 roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_launch=ab / tr["launches"],
-                                nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"])
+                                nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"],
+                                nodes_per_shadow_ray=counts["shadow_nodes"] / max(counts["shadow_rays"], 1))
         out = {
             "metric": "Mray/s (primary+bounce)", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -6,12 +6,12 @@
 // path state is a set of SoA ray streams in HBM spanning every pixel this GPU owns times the
 // accumulations in flight, and one bounce is three kernels:
 //
-//   k_trace_closest   Traverse            (BVH.hpp:309-360)     reads p,dir           writes tfar,primID
-//   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into
-//                     the next stream and NEE candidates into the shadow stream with wave64
-//                     ballot + mbcnt prefix sums (one atomic per wave per stream)
-//   k_trace_shadow    Traverse_shadow     (BVH.hpp:362-404) + Renderer.hpp:304-314 and the deferred
-//                     radiance finalisation ((R + unoccluded NEE) + emissive), in the reference's add order
+//   k_trace           Traverse (BVH.hpp:309-360) for the rays of bounce b: reads p,dir, writes tfar,primID — and, in the
+//                     same launch, Traverse_shadow (BVH.hpp:362-404) for the NEE rays of bounce b-1: one occlusion flag each
+//   k_shadow_resolve  Renderer.hpp:304-314 and the deferred radiance finalisation ((R + unoccluded NEE) + emissive),
+//                     in the reference's add order, for the shadow rays just traced
+//   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into the next stream and
+//                     NEE candidates into the shadow stream (wave64 ballot + mbcnt prefix sums, one atomic per workgroup)
 //
 // Per-path results do not depend on stream slot or scheduling: every random draw is re-derived from
 // (accumulations, seed[pixel], bounce) (Renderer.hpp:107,117,255,362), which is what lets the
@@ -470,34 +470,62 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // ------------------------------------------------------------------------------------------------
 // INTERSECTION — Traverse, BVH.hpp:309-360
 // ------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
-                                                               const uint32_t* __restrict__ count_ptr, uint32_t* work_next, DevCounters* ctr) {
-	extern __shared__ float4 lds[];
-	const uint32_t n = *count_ptr;
+// Drain one ray queue with the persistent-wave loop (dispatch on the staged-BVH variant).
+template <bool ANYHIT, bool COUNT, class LoadRay, class StoreResult>
+MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
+                         LoadRay load_ray, StoreResult store_result) {
 	if (n == 0) return;
-	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, static_cast<unsigned long long>(n));
-	uint32_t c_nodes = 0, c_spheres = 0;
+	const bool all = bvh_all_in_lds(sc);
+	if (sc.half_boxes) {
+		if (all) trace_persistent<ANYHIT, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+	} else {
+		if (all) trace_persistent<ANYHIT, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+	}
+}
+
+// INTERSECTION + SHADOW RAY TRACING in one launch: Traverse (BVH.hpp:309-360) for the rays of bounce b and
+// Traverse_shadow (BVH.hpp:362-404) for the NEE rays emitted at bounce b-1 — the two queues are independent, and every
+// launch ends with a tail while its longest rays finish (~180 us at 16k+ rays, measured), so draining both in one
+// persistent kernel halves the number of tails: a wave that runs out of closest-hit rays moves on to the shadow queue.
+// Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
+                                                       StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
+                                                       const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
+                                                       ShadowBuf sh, uint32_t* __restrict__ occ_out,
+                                                       const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, DevCounters* ctr) {
+	extern __shared__ float4 lds[];
+	const uint32_t nc = *closest_count, ns = *shadow_count;
+	if (nc + ns == 0) return;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		if (nc) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));
+		if (ns) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(ns));
+	}
+	uint32_t c_nodes = 0, c_spheres = 0, s_nodes = 0, s_spheres = 0;
 	if (sc.use_bvh && sc.n_recs != 0) {
-		if (blockIdx.x * 64u >= n) return;                           // more workgroups than minimum-size chunks: skip the staging too
+		if (static_cast<uint64_t>(blockIdx.x) * 64u >= static_cast<uint64_t>(nc) + ns) return;   // more workgroups than minimum-size chunks: skip the staging too
 		const TraceLds tl = stage_bvh(sc, lds);
-		auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-			px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
-		};
-		auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
-		const bool all = bvh_all_in_lds(sc);
-		if (sc.half_boxes) {
-			if (all) trace_persistent<false, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-			else trace_persistent<false, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		} else {
-			if (all) trace_persistent<false, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-			else trace_persistent<false, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		{
+			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
+				px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
+			};
+			auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
+			trace_queue<false, COUNT>(sc, tl, nc, closest_work, c_nodes, c_spheres, load_ray, store_result);
+		}
+		{
+			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
+				px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
+			};
+			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
+			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, s_nodes, s_spheres, load_ray, store_result);
 		}
 	} else {
-		if (blockIdx.x * kTraceBlock >= n) return;
-		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+		// brute force over all prims (the reference as shipped); also the no-spheres case
+		for (uint32_t base = blockIdx.x * kTraceBlock; base < nc; base += gridDim.x * kTraceBlock) {
 			const uint32_t i = base + threadIdx.x;
-			const bool active = i < n;
+			const bool active = i < nc;
 			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
 			if (active) { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
 			float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
@@ -505,8 +533,18 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_closest(SceneDev sc, Stre
 			if (sc.use_bvh == 0) traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
 			if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
 		}
+		for (uint32_t base = blockIdx.x * kTraceBlock; base < ns; base += gridDim.x * kTraceBlock) {
+			const uint32_t i = base + threadIdx.x;
+			const bool active = i < ns;
+			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
+			if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
+			bool occluded = false;
+			int32_t dummy = -1;
+			if (sc.use_bvh == 0) occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, s_spheres);
+			if (active) occ_out[i] = occluded ? 1u : 0u;
+		}
 	}
-	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
+	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); wave_sum(s_nodes, &ctr->shadow_nodes); wave_sum(s_spheres, &ctr->shadow_spheres); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -674,7 +712,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			out.path[slot] = path;
 		}
 		if (has_shadow) {
-			// radiance is finalised by k_trace_shadow once occlusion is known: (R + unoccluded NEE) + E
+			// radiance is finalised by k_shadow_resolve once k_trace has the occlusion flag: (R + unoccluded NEE) + E
 			sh.px[sslot] = P.x; sh.py[sslot] = P.y; sh.pz[sslot] = P.z;
 			sh.dx[sslot] = L.x; sh.dy[sslot] = L.y; sh.dz[sslot] = L.z;
 			sh.tfar[sslot] = light_distance;
@@ -697,47 +735,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 // ------------------------------------------------------------------------------------------------
 // SHADOW RAY TRACING + accumulation — Traverse_shadow (BVH.hpp:362-404), Renderer.hpp:304-314
 // ------------------------------------------------------------------------------------------------
-// Traverse_shadow (BVH.hpp:362-404): one occlusion flag per shadow ray.  The radiance adds that depend on it are done by
-// k_shadow_resolve, a plain streaming kernel, so the divergent traversal loop carries no extra memory traffic.
-template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_shadow(SceneDev sc, ShadowBuf sh, uint32_t* __restrict__ occ_out, uint32_t bounce,
-                                                              const uint32_t* __restrict__ shadow_count, uint32_t* work_next, DevCounters* ctr) {
-	extern __shared__ float4 lds[];
-	const uint32_t n = shadow_count[bounce];
-	if (n == 0) return;
-	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(n));
-	uint32_t c_nodes = 0, c_spheres = 0;
-	if (sc.use_bvh && sc.n_recs != 0) {
-		if (blockIdx.x * 64u >= n) return;
-		const TraceLds tl = stage_bvh(sc, lds);
-		auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-			px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
-		};
-		auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
-		const bool all = bvh_all_in_lds(sc);
-		if (sc.half_boxes) {
-			if (all) trace_persistent<true, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-			else trace_persistent<true, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		} else {
-			if (all) trace_persistent<true, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-			else trace_persistent<true, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		}
-	} else {
-		if (blockIdx.x * kTraceBlock >= n) return;
-		for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
-			const uint32_t i = base + threadIdx.x;
-			const bool active = i < n;
-			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
-			if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
-			bool occluded = false;
-			int32_t dummy = -1;
-			if (sc.use_bvh == 0) occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c_spheres);
-			if (active) occ_out[i] = occluded ? 1u : 0u;
-		}
-	}
-	if (COUNT) { wave_sum(c_nodes, &ctr->shadow_nodes); wave_sum(c_spheres, &ctr->shadow_spheres); }
-}
-
 // Shadow accumulation + deferred radiance finalisation: (R + unoccluded NEE) + emissive, the reference's add order
 // (Renderer.hpp:307-311, then 339-341 / 348-350), written to the next stream's radiance slot or added to the accumulator.
 __global__ __launch_bounds__(kBlock) void k_shadow_resolve(FrameParams fp, ShadowBuf sh, const uint32_t* __restrict__ occ, StreamBuf out, uint32_t bounce,

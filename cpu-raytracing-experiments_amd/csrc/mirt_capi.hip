@@ -75,7 +75,7 @@ struct mirt_ctx {
 	StreamBuf stream_buf[2]{};
 	ShadowBuf shadow_buf{};
 	float* hit_tfar = nullptr;
-	uint32_t* shadow_occ = nullptr;      // one occlusion flag per shadow ray (k_trace_shadow -> k_shadow_resolve)
+	uint32_t* shadow_occ = nullptr;      // one occlusion flag per shadow ray (k_trace -> k_shadow_resolve)
 	int32_t* hit_prim = nullptr;
 
 	// profiling
@@ -141,7 +141,7 @@ int ensure_streams(mirt_ctx* c) {
 	const size_t planes = 2 * 14 + 2 + 17 + 1;
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	HIP_TRY(c, c->arena.ensure(planes * plane_bytes));
-	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 4 + 4) * sizeof(uint32_t)));
+	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t)));
 	char* p = c->arena.as<char>();
 	auto take = [&]() { void* r = p; p += plane_bytes; return r; };
 	for (int b = 0; b < 2; b++) {
@@ -240,24 +240,30 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
 	const uint32_t tlds = trace_lds(c);
 
-	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 4) * sizeof(uint32_t), c->stream));
+	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t), c->stream));
 	{ Bracket t(c, MIRT_K_RAYGEN);
 	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], stream_count); }
+	// counts layout: stream_count[nb+1] | shadow_count[nb] | work_next[nb] | work_next_shadow[nb] | one always-zero word
+	const uint32_t* zero_count = work_next_shadow + nb;
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
 		const StreamBuf& in = c->stream_buf[bounce & 1u];
 		const StreamBuf& out = c->stream_buf[(bounce & 1u) ^ 1u];
+		const bool shadow_pending = fp.mis && bounce > 0;           // NEE rays emitted by k_shade(bounce-1)
 		{ Bracket t(c, MIRT_K_TRACE);
-		  if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce, ctr);
-		  else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce, ctr); }
+		  const uint32_t* sc_count = shadow_pending ? shadow_count + (bounce - 1) : zero_count;
+		  uint32_t* sc_work = work_next_shadow + (shadow_pending ? bounce - 1 : 0);
+		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce,
+		                                c->shadow_buf, c->shadow_occ, sc_count, sc_work, ctr);
+		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce,
+		                                c->shadow_buf, c->shadow_occ, sc_count, sc_work, ctr); }
+		if (shadow_pending) {
+			// the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
+			Bracket t(c, MIRT_K_SHADOW);
+			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->shadow_buf, c->shadow_occ, in, bounce - 1, shadow_count, accum, ctr);
+		}
 		{ Bracket t(c, MIRT_K_SHADE);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
-		if (fp.mis && bounce + 1 < nb) {
-			Bracket t(c, MIRT_K_SHADOW);
-			if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, c->shadow_buf, c->shadow_occ, bounce, shadow_count, work_next_shadow + bounce, ctr);
-			else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, c->shadow_buf, c->shadow_occ, bounce, shadow_count, work_next_shadow + bounce, ctr);
-			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->shadow_buf, c->shadow_occ, out, bounce, shadow_count, accum, ctr);
-		}
 	}
 	HIP_TRY(c, hipGetLastError());
 	c->accumulations += batch_n;
@@ -390,10 +396,8 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
 	{
 		const int lds_max = static_cast<int>(kLdsPerCu);
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_closest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_closest<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shadow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shadow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_shadow), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 	}
 	for (int k = 0; k < 3; k++) s.ambient[k] = ambient_color[k];
@@ -583,8 +587,8 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	DeviceBuffer rays, res, cnt;
-	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(8));
-	HIP_TRY(c, hipMemset(cnt.ptr, 0, 8));
+	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(16));
+	HIP_TRY(c, hipMemset(cnt.ptr, 0, 16));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
@@ -596,7 +600,9 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	DevCounters* scratch_ctr = nullptr;
 	DeviceBuffer ctr; HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
-	hipLaunchKernelGGL(k_trace_closest<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1, scratch_ctr);
+	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter }
+	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
+	                   ShadowBuf{}, static_cast<uint32_t*>(nullptr), cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
