@@ -13,6 +13,7 @@
 // The reference sorts centroids with the unstable std::ranges::sort (BVH.hpp:121); ties are broken by
 // primitive index here so the result is defined.
 #include "../../include/mirt.h"
+#include "bvh_build.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -33,8 +34,9 @@ struct Bounds {
 		}
 	}
 	float extent(int a) const { return hi[a] - lo[a]; }
-	float sah_area() const {                                  // Node::half_area(): 0 + d.y * d.z
-		float area = 0.0f;
+	float sah_area(bool full) const {
+		if (full) return (extent(0) * extent(1) + extent(1) * extent(2)) + extent(2) * extent(0);   // true half surface area (internal tree)
+		float area = 0.0f;                                    // Node::half_area() as written: 0 + d.y * d.z (Q15)
 		area += extent(1) * extent(2);
 		return area;
 	}
@@ -50,7 +52,7 @@ struct Pending { uint32_t node; size_t first, count; };
 
 class SweepBuilder {
 public:
-	SweepBuilder(const mirt_sphere* spheres, uint32_t n) : src_(spheres), n_(n), box_(n), suffix_cost_(n), left_side_(n) {
+	SweepBuilder(const mirt_sphere* spheres, uint32_t n, bool full_area = false) : src_(spheres), n_(n), full_area_(full_area), box_(n), suffix_cost_(n), left_side_(n) {
 		for (int a = 0; a < 3; a++) order_[a].resize(n);
 		std::vector<float> centre(static_cast<size_t>(n) * 3);
 		for (uint32_t i = 0; i < n; i++) {
@@ -69,7 +71,8 @@ public:
 		}
 	}
 
-	void run(std::vector<mirt_bvh_node>& nodes, mirt_sphere* prims_out) {
+	// prims_out (optional): primitives in leaf order; order_out (optional): source index of the primitive at each leaf slot
+	void run(std::vector<mirt_bvh_node>& nodes, mirt_sphere* prims_out, std::vector<uint32_t>* order_out = nullptr) {
 		nodes.clear();
 		bounds_.clear();
 		if (n_ == 0) return;
@@ -93,7 +96,7 @@ public:
 
 			const size_t lo_n = split.position - first, hi_n = last - split.position;
 			const Bounds lo_box = range_bounds(first, split.position), hi_box = range_bounds(split.position, last);
-			const bool hi_is_bigger_box = lo_box.sah_area() < hi_box.sah_area();
+			const bool hi_is_bigger_box = lo_box.sah_area(full_area_) < hi_box.sah_area(full_area_);
 			const bool hi_is_bigger_range = lo_n < hi_n;
 			// slot 0 gets the child with the larger (y*z) area
 			emit(nodes, hi_is_bigger_box ? hi_box : lo_box);
@@ -104,7 +107,8 @@ public:
 			todo.push_back(hi_is_bigger_range ? hi_job : lo_job);
 			todo.push_back(hi_is_bigger_range ? lo_job : hi_job);
 		}
-		for (uint32_t i = 0; i < n_; i++) prims_out[i] = src_[order_[0][i]];
+		if (prims_out) for (uint32_t i = 0; i < n_; i++) prims_out[i] = src_[order_[0][i]];
+		if (order_out) *order_out = order_[0];
 	}
 
 private:
@@ -122,18 +126,18 @@ private:
 	}
 	Candidate choose_split(const Bounds& parent, size_t first, size_t last) {
 		const size_t count = last - first;
-		Candidate best{ first + (count + 1) / 2, parent.widest_axis(), parent.sah_area() * (static_cast<float>(count) - 1.0f) };
+		Candidate best{ first + (count + 1) / 2, parent.widest_axis(), parent.sah_area(full_area_) * (static_cast<float>(count) - 1.0f) };
 		for (int axis = 0; axis < 3; axis++) {
 			const std::vector<uint32_t>& ids = order_[axis];
 			Bounds right = Bounds::nothing();
 			for (size_t i = last - 1; i > first; i--) {                              // suffix costs for splits at i
 				right.include(box_[ids[i]]);
-				suffix_cost_[i] = right.sah_area() * static_cast<float>(last - i);
+				suffix_cost_[i] = right.sah_area(full_area_) * static_cast<float>(last - i);
 			}
 			Bounds left = Bounds::nothing();
 			for (size_t i = first; i + 1 < last; i++) {
 				left.include(box_[ids[i]]);
-				const float left_cost = left.sah_area() * static_cast<float>(i + 1 - first);
+				const float left_cost = left.sah_area(full_area_) * static_cast<float>(i + 1 - first);
 				if (left_cost > best.cost) break;
 				const float total = left_cost + suffix_cost_[i + 1];
 				if (total < best.cost) best = Candidate{ i + 1, axis, total };
@@ -154,6 +158,7 @@ private:
 
 	const mirt_sphere* src_;
 	uint32_t n_;
+	bool full_area_;
 	std::vector<Bounds> box_;
 	std::vector<Bounds> bounds_;          // per emitted node
 	std::vector<float> suffix_cost_;
@@ -162,6 +167,14 @@ private:
 };
 
 } // namespace
+
+// Internal traversal tree: the same sweep builder with the true half surface area as cost (the reference's formula drops
+// the x extent, Q15, which roughly doubles the boxes a ray has to test).  Only the GPU-internal copy uses it; the
+// traversal result does not depend on the tree (DESIGN.md "Traversal semantics").
+void mirt_host::build_sah_tree(const mirt_sphere* prims, uint32_t n, std::vector<mirt_bvh_node>& nodes, std::vector<uint32_t>& prim_of_slot) {
+	SweepBuilder builder(prims, n, /*full_area=*/true);
+	builder.run(nodes, nullptr, &prim_of_slot);
+}
 
 extern "C" int mirt_bvh_build(const mirt_sphere* geometry, uint32_t n, mirt_bvh_node* nodes_out, uint32_t* n_nodes_out, mirt_sphere* prims_out) {
 	if ((!geometry && n) || !nodes_out || !n_nodes_out || (!prims_out && n)) return MIRT_ERR_ARG;

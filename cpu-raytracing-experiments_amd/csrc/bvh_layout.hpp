@@ -136,8 +136,12 @@ inline bool build_half_records(const std::vector<float>& recs, std::vector<uint3
 	return true;
 }
 
+// `prim_of_slot` (optional): leaf slot s of `nodes` refers to prims[prim_of_slot[s]] (internal tree); without it slot s is
+// prims[s] (the caller's tree, BVH.hpp:201-205).  Leaf references always carry the index into `prims` (the BVH-order
+// array hit.primID refers to); mapped leaves must hold a single prim.
 inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, const mirt_sphere* prims, uint32_t n_prims,
-                                 std::vector<float>& recs /* 16 floats per record */, uint32_t* max_depth_out) {
+                                 std::vector<float>& recs /* 16 floats per record */, uint32_t* max_depth_out,
+                                 const std::vector<uint32_t>* prim_of_slot = nullptr) {
 	recs.clear();
 	*max_depth_out = 0;
 	if (n_nodes == 0) return "";
@@ -149,7 +153,9 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		PadBox b{ { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
 		if (nd.prim_count != 0) {
 			if (nd.prim_count > 128) return "leaf with more than 128 prims";
-			for (uint32_t p = nd.first_id; p < nd.first_id + nd.prim_count; p++) {
+			if (prim_of_slot && nd.prim_count != 1) return "internal tree leaf with more than one prim";
+			for (uint32_t slot = nd.first_id; slot < nd.first_id + nd.prim_count; slot++) {
+				const uint32_t p = prim_of_slot ? (*prim_of_slot)[slot] : slot;
 				const float* c = prims[p].position;
 				const float r = std::sqrt(prims[p].radius_sq);
 				float amax = std::fabs(c[0]);
@@ -174,10 +180,11 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		std::memcpy(&q[12 + child], &ref, 4);
 	};
 	const PadBox nothing{ { FLT_MAX, FLT_MAX, FLT_MAX }, { FLT_MAX, FLT_MAX, FLT_MAX } };   // degenerate box at +max: every slab test misses it
+	auto leaf_of = [&](const mirt_bvh_node& nd) { return leaf_ref(prim_of_slot ? (*prim_of_slot)[nd.first_id] : nd.first_id, nd.prim_count); };
 	if (nodes[0].prim_count != 0) {                       // single-leaf tree: one record, second child empty
 		recs.assign(16, 0.0f);
-		put(0, 0, box[0], leaf_ref(nodes[0].first_id, nodes[0].prim_count));
-		put(0, 1, nothing, leaf_ref(nodes[0].first_id, 1));
+		put(0, 0, box[0], leaf_of(nodes[0]));
+		put(0, 1, nothing, leaf_of(nodes[0]));
 		*max_depth_out = 1;
 		return "";
 	}
@@ -200,7 +207,7 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		const uint32_t nd = order[r];
 		for (int child = 0; child < 2; child++) {
 			const uint32_t c = nodes[nd].first_id + child;
-			const uint32_t ref = nodes[c].prim_count ? leaf_ref(nodes[c].first_id, nodes[c].prim_count) : rec_of[c];
+			const uint32_t ref = nodes[c].prim_count ? leaf_of(nodes[c]) : rec_of[c];
 			put(r, child, box[c], ref);
 		}
 	}

@@ -10,6 +10,7 @@
 #include "../../include/mirt.h"
 #include "kernels.hpp"
 #include "bvh_layout.hpp"
+#include "bvh_build.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -368,8 +369,17 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	std::memcpy(sky.data(), hdri_rgba, sky.size() * sizeof(float4));
 	std::vector<float> recs;
 	uint32_t depth = 0;
-	{ const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
-	  if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str()); }
+	if (c->policy.reference_tree || n_spheres == 0) {
+		// traverse the caller's tree exactly as handed over (BVH.hpp:18-31 nodes over the BVH-order prims)
+		const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
+		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str());
+	} else {
+		// default: GPU-internal SAH tree over the same BVH-order prims (hit.primID keeps its meaning; results are identical)
+		std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
+		mirt_host::build_sah_tree(bvh_prims, n_spheres, own, prim_of_slot);
+		const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, &prim_of_slot);
+		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "internal BVH rejected: %s", why.c_str());
+	}
 	const uint32_t n_recs = static_cast<uint32_t>(recs.size() / 16);
 	std::vector<uint32_t> half_recs;
 	const bool half = c->allow_half && mirt_host::build_half_records(recs, half_recs);

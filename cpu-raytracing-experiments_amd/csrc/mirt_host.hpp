@@ -114,6 +114,7 @@ struct RendererPolicy {                                                    // Re
 	uint32_t buckets = 5;                                                  // AccumulationBuckets, Renderer.hpp:41
 	bool mis = true;                                                       // #define MIS true, Renderer.hpp:71
 	bool use_bvh = true;                                                   // reference ships USEBVH false (BVH.hpp:307); results are identical
+	bool reference_tree = false;                                           // true: traverse scene.acceleration_structure.nodes as is instead of the internal SAH tree
 };
 
 class Renderer {
@@ -123,7 +124,7 @@ public:
 	explicit Renderer(const Scene& scene_ref, RendererPolicy policy = {}, int device = 0) : scene(scene_ref) {
 		if (mirt_create(device, &ctx_) != MIRT_OK) throw std::runtime_error(std::string("mirt_create: ") + mirt_last_error(nullptr));
 		mirt_policy p{};
-		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh;
+		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh; p.reference_tree = policy.reference_tree;
 		check(mirt_set_policy(ctx_, &p), "mirt_set_policy");
 	}
 	~Renderer() { if (ctx_) mirt_destroy(ctx_); }

@@ -76,7 +76,8 @@ typedef struct mirt_policy {
 	uint32_t count_traffic; /* 1: kernels also count BVH nodes / spheres visited (slower; for the roofline's algorithmic bytes) */
 	uint32_t profile;       /* 1: bracket every kernel launch with HIP events (mirt_get_kernel_times) */
 	uint32_t max_batch;     /* accumulations kept in flight together, 0 = buckets (each lands in its own bucket) */
-	uint32_t _reserved;
+	uint32_t reference_tree;/* 0 (default): traverse a GPU-internal SAH tree built over the same BVH-order prims; 1: traverse the caller's
+	                         * nodes as handed over.  Results are identical either way (DESIGN.md "Traversal semantics"); read at mirt_set_scene. */
 } mirt_policy;
 
 typedef struct mirt_counters {

@@ -304,8 +304,10 @@ static inline Box box_empty() { return { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_M
 static inline void box_or(Box& a, const Box& b) {                             // :35-39 (glm::min/max(vec3))
 	for (int i = 0; i < 3; i++) { a.mn[i] = glm_min(a.mn[i], b.mn[i]); a.mx[i] = glm_max(a.mx[i], b.mx[i]); }
 }
+static bool g_experiment_true_area = false;   // true while building the mode-2 internal tree: full half area instead of the reference's Q15 formula
 static inline float box_half_area(const Box& b) {                             // :58-67 — Q15: only d.y*d.z
 	float d[3] = { b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2] };
+	if (g_experiment_true_area) return (d[0] * d[1] + d[1] * d[2]) + d[2] * d[0];      // csrc/bvh_build.cpp sah_area(full)
 	float area = 0.0f;
 	int32_t i = 2;
 	for (float accum = d[i--]; i > 0; i--) { area += d[i] * accum; accum += d[i]; }
@@ -322,10 +324,11 @@ struct BVH {
 	std::vector<Node> nodes;
 	std::vector<Sphere> prims;
 	std::vector<Box> padded;      // mode 2 only: conservative box per node (same indexing as nodes)
+	std::vector<uint32_t> slot_prim;   // mode 2 tree only: leaf slot -> index into the reference tree's prims (empty = identity)
 	float pad_rel = 0.0f;
 };
 
-static void bvh_build(const std::vector<Sphere>& primitives, BVH& out) {
+static void bvh_build(const std::vector<Sphere>& primitives, BVH& out, std::vector<uint32_t>* order_out = nullptr) {
 	struct StackFrame { size_t ID, begin, count; };
 	struct Split { size_t pos, axis; float cost; };
 	const size_t primnum = primitives.size();
@@ -414,6 +417,7 @@ static void bvh_build(const std::vector<Sphere>& primitives, BVH& out) {
 		stack.push_back({ first_child + (1 - combined), ranges[1 - sort_size].begin, ranges[1 - sort_size].end - ranges[1 - sort_size].begin });
 	}
 	for (size_t i = 0; i < primnum; i++) out.prims[i] = primitives[primIDs[i]];   // :201-205
+	if (order_out) order_out->assign(primIDs.begin(), primIDs.begin() + primnum);
 }
 
 // ---------------------------------------------------------------------------------
@@ -644,7 +648,7 @@ static void traverse_stream_shadow(const BVH& bvh, ShadowStream& in, size_t size
 // the closest-hit rule the result is then independent of visiting order and equals mode 0.
 static inline float next_up(float x) { return nextafterf(x, INFINITY); }
 static inline float next_dn(float x) { return nextafterf(x, -INFINITY); }
-static void bvh_pad(BVH& bvh, float pad_rel) {
+static void bvh_pad(BVH& bvh, const std::vector<Sphere>& prims, float pad_rel) {
 	const size_t n = bvh.nodes.size();
 	bvh.padded.assign(n, box_empty());
 	bvh.pad_rel = pad_rel;
@@ -652,8 +656,8 @@ static void bvh_pad(BVH& bvh, float pad_rel) {
 		const Node& nd = bvh.nodes[k];
 		Box b = box_empty();
 		if (nd.prim_count != 0) {
-			for (uint32_t p = nd.first_id; p < nd.first_id + nd.prim_count; p++) {
-				const Sphere& s = bvh.prims[p];
+			for (uint32_t slot = nd.first_id; slot < nd.first_id + nd.prim_count; slot++) {
+				const Sphere& s = prims[bvh.slot_prim.empty() ? slot : bvh.slot_prim[slot]];
 				const float c[3] = { s.px, s.py, s.pz };
 				const float r = sqrtf(s.radius_sq);
 				const float amax = std_max(std_max(fabsf(c[0]), fabsf(c[1])), fabsf(c[2]));
@@ -708,13 +712,14 @@ static inline void sphere_closest_tie(const Sphere& s, int32_t prim_ID, float px
 // Same step order as traverse_bvh() in csrc/kernels.hpp: at an inner node test both child boxes against the
 // current tfar; hit leaf children are intersected at once; inner children are re-checked against the possibly
 // shrunken tfar, the nearer one is entered first and the other pushed.  (The root box itself is not tested.)
-static inline void traverse_ray(const BVH& bvh, float px, float py, float pz, float dx, float dy, float dz,
+static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz,
                                 float* tfar, int32_t* primID, LocalCounters& lc) {
 	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
 	auto leaf = [&](const Node& n) {
-		for (uint32_t p = n.first_id; p < n.first_id + n.prim_count; p++) {
+		for (uint32_t slot = n.first_id; slot < n.first_id + n.prim_count; slot++) {
+			const uint32_t p = bvh.slot_prim.empty() ? slot : bvh.slot_prim[slot];
 			lc.spheres++;
-			sphere_closest_tie(bvh.prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
+			sphere_closest_tie(prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
 		}
 	};
 	if (bvh.nodes[0].prim_count != 0) {            // single-leaf tree: the GPU record holds the leaf's box as child 0
@@ -748,13 +753,13 @@ static inline void traverse_ray(const BVH& bvh, float px, float py, float pz, fl
 		id = stack[--sp];
 	}
 }
-static inline bool traverse_ray_shadow(const BVH& bvh, float px, float py, float pz, float dx, float dy, float dz,
+static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz,
                                        float tfar, LocalCounters& lc) {
 	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
 	auto leaf = [&](const Node& n) {
-		for (uint32_t p = n.first_id; p < n.first_id + n.prim_count; p++) {
+		for (uint32_t slot = n.first_id; slot < n.first_id + n.prim_count; slot++) {
 			lc.shadow_spheres++;
-			if (sphere_occludes(bvh.prims[p], px, py, pz, dx, dy, dz, tfar)) return true;
+			if (sphere_occludes(prims[bvh.slot_prim.empty() ? slot : bvh.slot_prim[slot]], px, py, pz, dx, dy, dz, tfar)) return true;
 		}
 		return false;
 	};
@@ -791,7 +796,9 @@ struct Oracle {
 	std::vector<int32_t> lights;          // Scene.hpp:9-17
 	Camera camera;
 	Sky sky;
-	BVH bvh;
+	BVH bvh;                              // the reference's tree (BVH.hpp:90-206): modes 0 and 1, and the prim order of every mode
+	BVH accel;                            // mode 2: the tree the HIP kernels traverse (internal SAH tree, or a copy of `bvh`)
+	bool accel_internal = true, accel_half = false;
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t accumulations = 0;
 	uint32_t max_bounces = 16;            // Renderer.hpp:24
@@ -810,9 +817,9 @@ static void traverse(const Oracle& o, const Buffer& in, Hit& out, size_t size, L
 	} else if (o.trav_mode == 1) {
 		if (!o.bvh.nodes.empty()) traverse_stream(o.bvh, in, out, size, lc);
 	} else {
-		if (!o.bvh.nodes.empty())
+		if (!o.accel.nodes.empty())
 			for (size_t i = 0; i < size; i++)
-				traverse_ray(o.bvh, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], &out.tfar[i], &out.primID[i], lc);
+				traverse_ray(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], &out.tfar[i], &out.primID[i], lc);
 	}
 	for (size_t i = 0; i < size; i++)                                                                          // :313-317 / :350-354
 		if (int32_t primID = out.primID[i]; primID >= 0) out.matID[i] = o.bvh.prims[primID].material_ID;
@@ -824,9 +831,9 @@ static void traverse_shadow(const Oracle& o, ShadowStream& in, size_t size, Loca
 	} else if (o.trav_mode == 1) {
 		if (!o.bvh.nodes.empty()) traverse_stream_shadow(o.bvh, in, size, lc);
 	} else {
-		if (!o.bvh.nodes.empty())
+		if (!o.accel.nodes.empty())
 			for (size_t i = 0; i < size; i++)
-				if (traverse_ray_shadow(o.bvh, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], in.tfar[i], lc))
+				if (traverse_ray_shadow(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], in.tfar[i], lc))
 					in.occluded.set(i);
 	}
 }
@@ -1103,6 +1110,23 @@ static int render(const Oracle& o, float* rgba) {
 // ---------------------------------------------------------------------------------
 // C interface for ctypes (tests / smoke / bench cpu_baseline only)
 // ---------------------------------------------------------------------------------
+// Mode-2 traversal tree = what csrc/mirt_capi.hip lays out for the GPU: by default an internal SAH tree (true half-area
+// cost) over the reference tree's prims, or the reference tree itself; boxes padded, optionally rounded outward to binary16.
+static void build_accel(Oracle& o) {
+	o.accel = BVH{};
+	if (o.accel_internal) {
+		g_experiment_true_area = true;
+		BVH tmp; std::vector<uint32_t> order;
+		bvh_build(o.bvh.prims, tmp, &order);
+		g_experiment_true_area = false;
+		o.accel.nodes = tmp.nodes; o.accel.slot_prim = order;
+	} else {
+		o.accel.nodes = o.bvh.nodes;
+	}
+	bvh_pad(o.accel, o.bvh.prims, 0x1p-18f);
+	if (o.accel_half) bvh_quantize_half(o.accel);
+}
+
 extern "C" {
 
 void* orc_create() { return new Oracle(); }
@@ -1120,7 +1144,7 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	o.sky.hdri.assign(hdri_rgba, hdri_rgba + static_cast<size_t>(hdri_w) * hdri_h * 4);
 	o.sky.fw = static_cast<float>(hdri_w - 1); o.sky.fh = static_cast<float>(hdri_h - 1);   // Application.cpp:230-231
 	bvh_build(o.geometry, o.bvh);
-	bvh_pad(o.bvh, 0x1p-18f);
+	build_accel(o);
 	o.lights.clear();
 	for (int32_t i = 0; i < n; i++) {
 		const float* em = o.material[o.geometry[i].material_ID].emission;
@@ -1128,8 +1152,9 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	}
 	return 0;
 }
-void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.bvh, pad_rel); }
-void orc_set_half_boxes(void* h, int half) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.bvh, o.bvh.pad_rel); if (half) bvh_quantize_half(o.bvh); }
+void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.accel, o.bvh.prims, pad_rel); if (o.accel_half) bvh_quantize_half(o.accel); }
+// internal_tree: 1 = internal SAH tree (product default), 0 = the reference tree; half: binary16 boxes (product's 32-B records)
+void orc_set_mode2_tree(void* h, int internal_tree, int half) { Oracle& o = *static_cast<Oracle*>(h); o.accel_internal = internal_tree != 0; o.accel_half = half != 0; build_accel(o); }
 int orc_node_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->bvh.nodes.size()); }
 int orc_light_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->lights.size()); }
 void orc_get_bvh(void* h, void* nodes, void* prims) {
@@ -1201,7 +1226,7 @@ void orc_trace_closest(void* h, int trav_mode, size_t n, const float* p_xyz, con
 		const float px = p_xyz[i], py = p_xyz[n + i], pz = p_xyz[2 * n + i];
 		const float dx = dir_xyz[i], dy = dir_xyz[n + i], dz = dir_xyz[2 * n + i];
 		if (trav_mode == 0) { for (size_t p = 0; p < o.bvh.prims.size(); p++) sphere_closest(o.bvh.prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, &t, &id); }
-		else if (!o.bvh.nodes.empty()) traverse_ray(o.bvh, px, py, pz, dx, dy, dz, &t, &id, lc);
+		else if (!o.accel.nodes.empty()) traverse_ray(o.accel, o.bvh.prims, px, py, pz, dx, dy, dz, &t, &id, lc);
 		tfar[i] = t; primID[i] = id;
 	}
 }
@@ -1213,7 +1238,7 @@ void orc_trace_shadow(void* h, int trav_mode, size_t n, const float* p_xyz, cons
 		const float dx = dir_xyz[i], dy = dir_xyz[n + i], dz = dir_xyz[2 * n + i];
 		bool occ = false;
 		if (trav_mode == 0) { for (size_t p = 0; p < o.bvh.prims.size() && !occ; p++) occ = sphere_occludes(o.bvh.prims[p], px, py, pz, dx, dy, dz, tfar[i]); }
-		else if (!o.bvh.nodes.empty()) occ = traverse_ray_shadow(o.bvh, px, py, pz, dx, dy, dz, tfar[i], lc);
+		else if (!o.accel.nodes.empty()) occ = traverse_ray_shadow(o.accel, o.bvh.prims, px, py, pz, dx, dy, dz, tfar[i], lc);
 		occluded[i] = occ ? 1 : 0;
 	}
 }

@@ -185,24 +185,33 @@ def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
     assert cg["rays"] == co["rays"] and cg["terminated"] == co["terminated"]
     if scene_name != "S8a":
         # same traversal algorithm as the oracle's mode 2 -> same visit counts (feeds the roofline's algorithmic bytes)
-        t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.set_half_boxes(r.debug_info()["half_boxes"]); t.Resize(w, h); t.Accumulate(spp)
+        t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(w, h); t.Accumulate(spp)
         ct = t.counters()
         assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
     r.close()
 
 
 @pytest.mark.parametrize("allow_half", [True, False])
-def test_record_formats_agree(mirt, allow_half):
-    """binary16 (32-B) and f32 (64-B) BVH records are both only conservative culling structures: same accumulators."""
+@pytest.mark.parametrize("reference_tree", [False, True])
+def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
+    """The GPU-internal BVH is only a conservative culling structure: binary16 (32-B) or f32 (64-B) records, the internal
+    SAH tree or the caller's reference tree — all must give the brute-force accumulators, and visit exactly the boxes and
+    spheres the oracle's twin visits for the same variant."""
     sc = mirt.scene.synthetic(1000, ambient=0.5)
     o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(128, 128); o.Accumulate(5)
-    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, count_traffic=True); r.Resize(128, 128); r.Accumulate(5)
+    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, reference_tree=reference_tree, count_traffic=True)
+    r.Resize(128, 128); r.Accumulate(5)
     info = r.debug_info()
     assert info["half_boxes"] == int(allow_half) and info["records"] == 999 and info["lds_records"] == 999 and info["lds_spheres"] == 1000
     assert info["trace_workgroups_per_cu"] == (2 if allow_half else 1)
-    assert_same(r.accumulator(), o.accumulator(), f"accumulator (half={allow_half})")
-    t = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH); t.set_half_boxes(allow_half); t.Resize(128, 128); t.Accumulate(5)
-    assert r.counters()["nodes"] == t.counters()["nodes"] and r.counters()["spheres"] == t.counters()["spheres"]
+    assert_same(r.accumulator(), o.accumulator(), f"accumulator (half={allow_half}, reference_tree={reference_tree})")
+    t = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(128, 128); t.Accumulate(5)
+    cg, ct = r.counters(), t.counters()
+    assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
+    if not reference_tree:
+        ref = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, count_traffic=True); ref.Resize(128, 128); ref.Accumulate(5)
+        assert cg["nodes"] < 0.6 * ref.counters()["nodes"]          # the internal SAH tree roughly halves the box tests
+        ref.close()
     r.close()
 
 
