@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=None, help="accumulations per step (default: cfg2's 64)")
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the counting replay (roofline.achieved becomes null)")
     args = ap.parse_args()
@@ -107,7 +108,8 @@ def main():
     first, count = mirt.distributed.tile_range(tiles, rank, world)
 
     r = mirt.Renderer(scene_fn(), device=local_rank, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True,
-                      use_bvh=bool(cfg["use_bvh"]), profile=True)
+                      use_bvh=bool(cfg["use_bvh"]), profile=True, streams=args.streams)
+    n_streams = args.streams or 3
     r.Resize(width, height)
     if world > 1:
         r.SetTileRange(first, count)
@@ -148,6 +150,20 @@ def main():
         if rank == 0:
             assert tuple(full.shape) == (tiles, cfg["buckets"], 3, 256)
 
+    # ---- roofline pass: the same W+K steps with ONE batch in flight, so every launch has the GPU to itself and its HIP-event
+    #      duration is the kernel's own (in the pipelined pass above a launch's duration includes time shared with the
+    #      other streams' kernels; those figures are reported as well, as "overlapped") ----
+    ktimes_serial = None
+    if n_streams != 1 and not args.no_counts:
+        r.set_policy(streams=1, profile=1, count_traffic=0)
+        r.ResetAccumulator()
+        for _ in range(W):
+            r.Accumulate(spp)
+        r.kernel_times(reset=True)
+        for _ in range(K):
+            r.Accumulate(spp)
+        ktimes_serial = r.kernel_times(reset=True)
+
     # ---- counting replay of the same steps: rays / nodes / spheres of exactly the timed accumulation indices ----
     counts = None
     if not args.no_counts:
@@ -160,8 +176,6 @@ def main():
             r.Accumulate(spp)
         c1 = r.counters()
         counts = {k: c1[k] - c0[k] for k in c1}
-    else:
-        counts = None
     rays_local = counts["rays"] if counts else None
     if rays_local is None:                                  # rays are counted in every mode
         c = r.counters(); rays_local = c["rays"] * K // (K + W)
@@ -174,17 +188,32 @@ def main():
     if rank == 0:
         value = rays_total / elapsed / 1e6
         roofline = None
-        tr = ktimes["trace"]
+        kt = ktimes_serial or ktimes
+        tr = kt["trace"]
         if tr["launches"]:
             avg_ms = tr["ms"] / tr["launches"]
             roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
-                        "traffic": None, "launches": tr["launches"], "avg_launch_ms": avg_ms}
+                        "traffic": None, "launches": tr["launches"], "avg_launch_ms": avg_ms,
+                        "measured_with": ("second live pass of the same steps with streams=1 (one kernel on the GPU at a time)" if ktimes_serial
+                                          else "the timed pass (streams=1)")}
             if counts:
                 ab = algorithmic_bytes(counts)
                 ach = ab / (tr["ms"] * 1e-3) / 1e9
                 roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_launch=ab / tr["launches"],
                                 nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"],
                                 nodes_per_shadow_ray=counts["shadow_nodes"] / max(counts["shadow_rays"], 1))
+                if ktimes_serial:
+                    ov = ktimes["trace"]
+                    roofline["overlapped"] = {"avg_launch_ms": ov["ms"] / ov["launches"], "achieved": ab / (ov["ms"] * 1e-3) / 1e9,
+                                              "frac": ab / (ov["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              "note": f"same launches during the value pass, {n_streams} batches in flight: durations include time shared with other kernels"}
+            traffic_file = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+            if os.path.exists(traffic_file):
+                try:
+                    roofline["traffic"] = json.load(open(traffic_file))["kernels"]["mirt::k_trace<false>"]["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+                except Exception:
+                    pass
         out = {
             "metric": "Mray/s (primary+bounce)", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -192,10 +221,10 @@ def main():
             "config": {"workload": "cfg2: S(1000) spheres + SAH BVH, MIS, Policy.max_bounces=5 (primary+4 bounces), "
                                    f"{spp} accumulations/step, 1024x1024 px per GPU", "image": f"{width}x{height}",
                        "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
-                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU", "batches_in_flight": n_streams},
             "rays_per_step": rays_total / K,
             "shadow_rays_per_step": (counts["shadow_rays"] / K) if counts else None,
-            "kernel_ms_per_step": {k: v["ms"] / K for k, v in ktimes.items() if v["launches"]},
+            "kernel_ms_per_step": {k: v["ms"] / K for k, v in (ktimes_serial or ktimes).items() if v["launches"]},
             "gather_ms": gather_ms,
             "roofline": roofline,
         }

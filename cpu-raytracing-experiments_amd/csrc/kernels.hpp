@@ -752,6 +752,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow_resolve(FrameParams fp, Shado
 	wave_sum(c_term, &ctr->terminated);
 }
 
+// In-order merge of one batch's contribution buffer into the accumulator (see launch_batch in mirt_capi.hip): exactly the
+// `output_color[px] += radiance` of Renderer.hpp:427-429, one add per (pixel, bucket) per Accumulate() call, applied in
+// accumulation order; entries the batch did not touch hold +0 and leave the accumulator unchanged.
+__global__ __launch_bounds__(kBlock) void k_merge_contrib(float4* __restrict__ accum, const float4* __restrict__ contrib, size_t n4) {
+	for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * kBlock) {
+		float4 a = accum[i]; const float4 c = contrib[i];
+		a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+		accum[i] = a;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // MEDIAN OF MEANS & TONEMAPPING — Renderer::Render, Renderer.hpp:436-478
 // ------------------------------------------------------------------------------------------------

@@ -43,6 +43,22 @@ struct DeviceBuffer {
 
 struct TimedLaunch { int klass; hipEvent_t start, stop; };
 
+// One batch in flight: its own HIP stream, ray streams and (when more than one slot exists) contribution buffer.
+struct PipeSlot {
+	hipStream_t stream = nullptr;
+	DeviceBuffer arena;              // ray streams
+	DeviceBuffer counts;             // stream_count[nb+1] | shadow_count[nb] | work_next[nb] | work_next_shadow[nb] | zero word
+	DeviceBuffer contrib;            // this batch's adds, same layout as the accumulator
+	hipEvent_t batch_done = nullptr; // recorded on `stream` after the batch's last kernel
+	hipEvent_t merged = nullptr;     // recorded on the main stream after the batch was merged (slot reusable)
+	bool in_use = false;
+	StreamBuf stream_buf[2]{};
+	ShadowBuf shadow_buf{};
+	float* hit_tfar = nullptr;
+	int32_t* hit_prim = nullptr;
+	uint32_t* shadow_occ = nullptr;  // one occlusion flag per shadow ray (k_trace -> k_shadow_resolve)
+};
+
 } // namespace
 
 struct mirt_ctx {
@@ -51,7 +67,7 @@ struct mirt_ctx {
 	hipStream_t stream = nullptr;
 	std::string error;
 
-	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0 };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
+	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, { 0, 0, 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t first_tile = 0, n_tiles = 0;
 	uint32_t accumulations = 0;
@@ -68,16 +84,11 @@ struct mirt_ctx {
 	// frame state
 	DeviceBuffer accumulator;        // [local tile][bucket][3][256] f32
 	DeviceBuffer framebuffer;        // width*height float4
-	DeviceBuffer arena;              // ray streams
-	DeviceBuffer counts;             // stream_count[max_bounces+1] ++ shadow_count[max_bounces]
 	DeviceBuffer counters;           // DevCounters
+	std::vector<PipeSlot> slots;     // batches in flight (policy.streams)
 	uint32_t capacity = 0;           // rays per stream plane
 	uint32_t arena_bounces = 0;
-	StreamBuf stream_buf[2]{};
-	ShadowBuf shadow_buf{};
-	float* hit_tfar = nullptr;
-	uint32_t* shadow_occ = nullptr;      // one occlusion flag per shadow ray (k_trace -> k_shadow_resolve)
-	int32_t* hit_prim = nullptr;
+	uint64_t batch_seq = 0;
 
 	// profiling
 	std::vector<TimedLaunch> pending;
@@ -129,7 +140,13 @@ uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 	return static_cast<uint32_t>(blocks);
 }
 
-// Carve the frame-wide ray streams out of one allocation.
+hipError_t sync_all(mirt_ctx* c) {
+	for (PipeSlot& sl : c->slots) if (sl.stream) { hipError_t e = hipStreamSynchronize(sl.stream); if (e != hipSuccess) return e; }
+	return hipStreamSynchronize(c->stream);
+}
+uint32_t wanted_slots(const mirt_ctx* c) { const uint32_t s = c->policy.streams ? c->policy.streams : 3u; return s > 8u ? 8u : s; }
+
+// Carve each slot's frame-wide ray streams out of one allocation.
 int ensure_streams(mirt_ctx* c) {
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
 	const uint64_t cap64 = n_pix * batch_limit(c);
@@ -138,30 +155,52 @@ int ensure_streams(mirt_ctx* c) {
 	if (cap64 >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);
 	const uint32_t cap = static_cast<uint32_t>(cap64);
 	const uint32_t nb = c->policy.max_bounces;
-	if (cap == c->capacity && nb == c->arena_bounces && c->arena.ptr) return MIRT_OK;
+	const uint32_t want = wanted_slots(c);
+	const size_t acc_bytes = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize * sizeof(float);
+	if (cap == c->capacity && nb == c->arena_bounces && c->slots.size() == want && (want == 1 || c->slots[0].contrib.bytes >= acc_bytes)) return MIRT_OK;
+	HIP_TRY(c, sync_all(c));
+	while (c->slots.size() > want) {
+		PipeSlot& sl = c->slots.back();
+		sl.arena.release(); sl.counts.release(); sl.contrib.release();
+		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
+		if (sl.merged) (void)hipEventDestroy(sl.merged);
+		if (sl.stream) (void)hipStreamDestroy(sl.stream);
+		c->slots.pop_back();
+	}
+	while (c->slots.size() < want) {
+		PipeSlot sl;
+		HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+		HIP_TRY(c, hipEventCreateWithFlags(&sl.batch_done, hipEventDisableTiming));
+		HIP_TRY(c, hipEventCreateWithFlags(&sl.merged, hipEventDisableTiming));
+		c->slots.push_back(sl);
+	}
 	const size_t planes = 2 * 14 + 2 + 17 + 1;
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
-	HIP_TRY(c, c->arena.ensure(planes * plane_bytes));
-	HIP_TRY(c, c->counts.ensure((static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t)));
-	char* p = c->arena.as<char>();
-	auto take = [&]() { void* r = p; p += plane_bytes; return r; };
-	for (int b = 0; b < 2; b++) {
-		StreamBuf& s = c->stream_buf[b];
-		s.px = (float*)take(); s.py = (float*)take(); s.pz = (float*)take();
-		s.dx = (float*)take(); s.dy = (float*)take(); s.dz = (float*)take();
-		s.tr = (float*)take(); s.tg = (float*)take(); s.tb = (float*)take();
-		s.rr = (float*)take(); s.rg = (float*)take(); s.rb = (float*)take();
-		s.pdf = (float*)take(); s.path = (uint32_t*)take();
+	for (PipeSlot& sl : c->slots) {
+		sl.in_use = false;
+		HIP_TRY(c, sl.arena.ensure(planes * plane_bytes));
+		HIP_TRY(c, sl.counts.ensure((static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t)));
+		if (want > 1) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
+		char* p = sl.arena.as<char>();
+		auto take = [&]() { void* r = p; p += plane_bytes; return r; };
+		for (int b = 0; b < 2; b++) {
+			StreamBuf& s = sl.stream_buf[b];
+			s.px = (float*)take(); s.py = (float*)take(); s.pz = (float*)take();
+			s.dx = (float*)take(); s.dy = (float*)take(); s.dz = (float*)take();
+			s.tr = (float*)take(); s.tg = (float*)take(); s.tb = (float*)take();
+			s.rr = (float*)take(); s.rg = (float*)take(); s.rb = (float*)take();
+			s.pdf = (float*)take(); s.path = (uint32_t*)take();
+		}
+		sl.hit_tfar = (float*)take(); sl.hit_prim = (int32_t*)take();
+		ShadowBuf& h = sl.shadow_buf;
+		h.px = (float*)take(); h.py = (float*)take(); h.pz = (float*)take();
+		h.dx = (float*)take(); h.dy = (float*)take(); h.dz = (float*)take(); h.tfar = (float*)take();
+		h.sr = (float*)take(); h.sg = (float*)take(); h.sb = (float*)take();
+		h.rr = (float*)take(); h.rg = (float*)take(); h.rb = (float*)take();
+		h.er = (float*)take(); h.eg = (float*)take(); h.eb = (float*)take();
+		h.dest = (uint32_t*)take();
+		sl.shadow_occ = (uint32_t*)take();
 	}
-	c->hit_tfar = (float*)take(); c->hit_prim = (int32_t*)take();
-	ShadowBuf& h = c->shadow_buf;
-	h.px = (float*)take(); h.py = (float*)take(); h.pz = (float*)take();
-	h.dx = (float*)take(); h.dy = (float*)take(); h.dz = (float*)take(); h.tfar = (float*)take();
-	h.sr = (float*)take(); h.sg = (float*)take(); h.sb = (float*)take();
-	h.rr = (float*)take(); h.rg = (float*)take(); h.rb = (float*)take();
-	h.er = (float*)take(); h.eg = (float*)take(); h.eb = (float*)take();
-	h.dest = (uint32_t*)take();
-	c->shadow_occ = (uint32_t*)take();
 	c->capacity = cap;
 	c->arena_bounces = nb;
 	return MIRT_OK;
@@ -169,10 +208,12 @@ int ensure_streams(mirt_ctx* c) {
 
 int alloc_accumulator(mirt_ctx* c) {
 	const size_t floats = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize;
+	HIP_TRY(c, sync_all(c));
 	HIP_TRY(c, c->accumulator.ensure(floats * sizeof(float)));
 	if (floats) HIP_TRY(c, hipMemsetAsync(c->accumulator.ptr, 0, floats * sizeof(float), c->stream));
 	HIP_TRY(c, hipMemsetAsync(c->counters.ptr, 0, sizeof(DevCounters), c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (PipeSlot& sl : c->slots) sl.in_use = false;
 	c->accumulations = 0;
 	return MIRT_OK;
 }
@@ -186,7 +227,7 @@ hipEvent_t take_event(mirt_ctx* c) {
 }
 void harvest(mirt_ctx* c) {
 	if (c->pending.empty()) return;
-	(void)hipStreamSynchronize(c->stream);
+	(void)sync_all(c);
 	for (TimedLaunch& t : c->pending) {
 		float ms = 0.0f;
 		if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) { c->times.ms[t.klass] += ms; c->times.launches[t.klass]++; }
@@ -195,12 +236,12 @@ void harvest(mirt_ctx* c) {
 	c->pending.clear();
 }
 struct Bracket {
-	mirt_ctx* c; int klass; hipEvent_t a = nullptr, b = nullptr;
-	Bracket(mirt_ctx* ctx, int k) : c(ctx), klass(k) {
-		if (c->policy.profile) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, c->stream); }
+	mirt_ctx* c; int klass; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+	Bracket(mirt_ctx* ctx, int k, hipStream_t stream = nullptr) : c(ctx), klass(k), st(stream ? stream : ctx->stream) {
+		if (c->policy.profile) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, st); }
 	}
 	~Bracket() {
-		if (c->policy.profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back(TimedLaunch{ klass, a, b }); }
+		if (c->policy.profile) { (void)hipEventRecord(b, st); c->pending.push_back(TimedLaunch{ klass, a, b }); }
 	}
 };
 
@@ -219,20 +260,30 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	return fp;
 }
 
-// One batch = up to `buckets` consecutive Accumulate() calls in flight together; consecutive
-// accumulation indices land in distinct buckets (Renderer.hpp:82), so no two paths of a batch
-// touch the same accumulator word.
+// One batch = up to `buckets` consecutive Accumulate() calls in flight together; consecutive accumulation indices land
+// in distinct buckets (Renderer.hpp:82), so no two paths of a batch touch the same accumulator word.
+//
+// Batches themselves are independent except for the ORDER of their adds into a bucket, so up to policy.streams of them
+// run concurrently, each on its own HIP stream with its own ray streams: every trace launch ends in a tail while its
+// longest rays finish (~0.2 ms with most of the chip idle), and late bounces are thin; a second and third batch fill
+// those holes (+49 % throughput with 3 streams on cfg2).  To keep the reference's add order each in-flight batch adds
+// into a zeroed contribution buffer, and the buffers are merged into the accumulator on the main stream in batch order.
 int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const FrameParams fp = frame_params(c, c->accumulations, batch_n);
 	const uint32_t nb = c->policy.max_bounces;
 	const uint64_t total = static_cast<uint64_t>(fp.n_pix) * batch_n;
 	if (total == 0) return MIRT_OK;
-	uint32_t* stream_count = c->counts.as<uint32_t>();
+	const bool pipelined = c->slots.size() > 1;
+	PipeSlot& sl = c->slots[c->batch_seq % c->slots.size()];
+	hipStream_t st = pipelined ? sl.stream : c->stream;
+	const size_t acc_floats = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize;
+	uint32_t* stream_count = sl.counts.as<uint32_t>();
 	uint32_t* shadow_count = stream_count + nb + 1;
 	uint32_t* work_next = shadow_count + nb;            // per-launch work counters of the persistent trace kernels
 	uint32_t* work_next_shadow = work_next + nb;
+	const uint32_t* zero_count = work_next_shadow + nb; // an always-zero count ("no shadow rays pending")
 	DevCounters* ctr = c->counters.as<DevCounters>();
-	float* accum = c->accumulator.as<float>();
+	float* accum = pipelined ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
 	sc.use_bvh = c->policy.use_bvh;
 	const bool count = c->policy.count_traffic != 0;
@@ -241,32 +292,45 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
 	const uint32_t tlds = trace_lds(c);
 
-	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t), c->stream));
-	{ Bracket t(c, MIRT_K_RAYGEN);
-	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], stream_count); }
-	// counts layout: stream_count[nb+1] | shadow_count[nb] | work_next[nb] | work_next_shadow[nb] | one always-zero word
-	const uint32_t* zero_count = work_next_shadow + nb;
+	if (pipelined) {
+		if (sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));      // the slot's previous batch has been merged: buffers are free
+		HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, acc_floats * sizeof(float), st));
+	}
+	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t), st));
+	{ Bracket t(c, MIRT_K_RAYGEN, st);
+	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, st, fp, sl.stream_buf[0], stream_count); }
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
-		const StreamBuf& in = c->stream_buf[bounce & 1u];
-		const StreamBuf& out = c->stream_buf[(bounce & 1u) ^ 1u];
+		const StreamBuf& in = sl.stream_buf[bounce & 1u];
+		const StreamBuf& out = sl.stream_buf[(bounce & 1u) ^ 1u];
 		const bool shadow_pending = fp.mis && bounce > 0;           // NEE rays emitted by k_shade(bounce-1)
-		{ Bracket t(c, MIRT_K_TRACE);
+		{ Bracket t(c, MIRT_K_TRACE, st);
 		  const uint32_t* sc_count = shadow_pending ? shadow_count + (bounce - 1) : zero_count;
 		  uint32_t* sc_work = work_next_shadow + (shadow_pending ? bounce - 1 : 0);
-		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce,
-		                                c->shadow_buf, c->shadow_occ, sc_count, sc_work, ctr);
-		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, c->stream, sc, in, c->hit_tfar, c->hit_prim, stream_count + bounce, work_next + bounce,
-		                                c->shadow_buf, c->shadow_occ, sc_count, sc_work, ctr); }
+		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
+		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, ctr);
+		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
+		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, ctr); }
 		if (shadow_pending) {
 			// the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-			Bracket t(c, MIRT_K_SHADOW);
-			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, c->stream, fp, c->shadow_buf, c->shadow_occ, in, bounce - 1, shadow_count, accum, ctr);
+			Bracket t(c, MIRT_K_SHADOW, st);
+			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, st, fp, sl.shadow_buf, sl.shadow_occ, in, bounce - 1, shadow_count, accum, ctr);
 		}
-		{ Bracket t(c, MIRT_K_SHADE);
-		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
-		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, c->stream, sc, fp, in, c->hit_tfar, c->hit_prim, out, c->shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
+		{ Bracket t(c, MIRT_K_SHADE, st);
+		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
+		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
 	}
 	HIP_TRY(c, hipGetLastError());
+	if (pipelined) {
+		// merges are enqueued on the main stream in batch order => every bucket receives its adds in accumulation order
+		HIP_TRY(c, hipEventRecord(sl.batch_done, st));
+		HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.batch_done, 0));
+		{ Bracket t(c, MIRT_K_RESOLVE);
+		  hipLaunchKernelGGL(k_merge_contrib, dim3(grid_for(c, acc_floats / 4)), dim3(kBlock), 0, c->stream, c->accumulator.as<float4>(), sl.contrib.as<float4>(), acc_floats / 4); }
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipEventRecord(sl.merged, c->stream));
+		sl.in_use = true;
+	}
+	c->batch_seq++;
 	c->accumulations += batch_n;
 	if (c->policy.profile && c->pending.size() > 512) harvest(c);
 	return MIRT_OK;
@@ -317,11 +381,18 @@ int mirt_create(int device, mirt_ctx** out) {
 int mirt_destroy(mirt_ctx* c) {
 	if (!c) return MIRT_ERR_ARG;
 	(void)hipSetDevice(c->device);
-	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	(void)sync_all(c);
 	harvest(c);
+	for (PipeSlot& sl : c->slots) {
+		sl.arena.release(); sl.counts.release(); sl.contrib.release();
+		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
+		if (sl.merged) (void)hipEventDestroy(sl.merged);
+		if (sl.stream) (void)hipStreamDestroy(sl.stream);
+	}
+	c->slots.clear();
 	for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
 	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->geom, &c->geom_mat, &c->mat_albedo, &c->mat_emission, &c->lights,
-	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->arena, &c->counts, &c->counters };
+	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->counters };
 	for (DeviceBuffer* b : bufs) b->release();
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -435,7 +506,7 @@ int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
 	if (p->max_bounces < 1 || p->max_bounces > 1024) return fail(c, MIRT_ERR_ARG, "max_bounces %u out of range", p->max_bounces);
 	if (p->buckets < 1 || p->buckets > MIRT_MAX_BUCKETS) return fail(c, MIRT_ERR_ARG, "buckets %u out of range 1..%u", p->buckets, MIRT_MAX_BUCKETS);
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	const bool realloc_acc = p->buckets != c->policy.buckets;
 	c->policy = *p;
 	if (realloc_acc && c->n_tiles) { int r = alloc_accumulator(c); if (r) return r; }
@@ -447,7 +518,7 @@ int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
 	if (!c) return MIRT_ERR_ARG;
 	if (width > 65536 || height > 65536) return fail(c, MIRT_ERR_ARG, "size %ux%u too large", width, height);
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	c->width = width; c->height = height;
 	c->h_tiles = width / MIRT_TILE_ROOT; c->v_tiles = height / MIRT_TILE_ROOT;          // Renderer.hpp:59-60
 	c->first_tile = 0; c->n_tiles = c->h_tiles * c->v_tiles;
@@ -461,7 +532,7 @@ int mirt_set_tile_range(mirt_ctx* c, uint32_t first_tile, uint32_t n_tiles) {
 	const uint64_t all = static_cast<uint64_t>(c->h_tiles) * c->v_tiles;
 	if (static_cast<uint64_t>(first_tile) + n_tiles > all) return fail(c, MIRT_ERR_ARG, "tile range [%u,+%u) exceeds %llu tiles", first_tile, n_tiles, (unsigned long long)all);
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	c->first_tile = first_tile; c->n_tiles = n_tiles;
 	return alloc_accumulator(c);
 }
@@ -487,7 +558,7 @@ int mirt_accumulate_async(mirt_ctx* c, uint32_t n_calls) {
 int mirt_synchronize(mirt_ctx* c) {
 	if (!c) return MIRT_ERR_ARG;
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	return MIRT_OK;
 }
 int mirt_accumulate(mirt_ctx* c, uint32_t n_calls) {
@@ -506,7 +577,7 @@ int mirt_read_accumulator(mirt_ctx* c, float* dst) {
 	if (!c || !dst) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	if (n) HIP_TRY(c, hipMemcpy(dst, c->accumulator.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
 	return MIRT_OK;
 }
@@ -520,7 +591,7 @@ int mirt_load_accumulator(mirt_ctx* c, const float* src, int src_is_device, uint
 	if (!c || !src) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	if (n) HIP_TRY(c, hipMemcpy(c->accumulator.ptr, src, n * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 	c->accumulations = accumulations;
 	return MIRT_OK;
@@ -534,6 +605,7 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 	HIP_TRY(c, hipSetDevice(c->device));
 	const float scale = c->camera.exposure / static_cast<float>(c->accumulations / k);              // Renderer.hpp:439
 	const uint32_t n_pix = c->n_tiles * kTileSize;
+	HIP_TRY(c, sync_all(c));
 	{ Bracket t(c, MIRT_K_RESOLVE);
 	  hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n_pix)), dim3(kBlock), 0, c->stream, c->accumulator.as<float>(), c->framebuffer.as<float4>(),
 	                     n_pix, c->first_tile, c->h_tiles, c->width, k, scale); }
@@ -554,7 +626,7 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 int mirt_get_counters(mirt_ctx* c, mirt_counters* out) {
 	if (!c || !out) return MIRT_ERR_ARG;
 	HIP_TRY(c, hipSetDevice(c->device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	HIP_TRY(c, sync_all(c));
 	DevCounters d;
 	HIP_TRY(c, hipMemcpy(&d, c->counters.ptr, sizeof d, hipMemcpyDeviceToHost));
 	out->rays = d.rays; out->shadow_rays = d.shadow_rays; out->nodes = d.nodes; out->spheres = d.spheres;
@@ -579,10 +651,11 @@ int mirt_debug_raygen(mirt_ctx* c, uint32_t accumulations, float* p_xyz, float* 
 	if ((r = ensure_streams(c))) return r;
 	const FrameParams fp = frame_params(c, accumulations - 1, 1);
 	const size_t n = fp.n_pix;
-	hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, fp, c->stream_buf[0], c->counts.as<uint32_t>());
+	HIP_TRY(c, sync_all(c));
+	hipLaunchKernelGGL(k_raygen, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, fp, c->slots[0].stream_buf[0], c->slots[0].counts.as<uint32_t>());
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	const StreamBuf& s = c->stream_buf[0];
+	const StreamBuf& s = c->slots[0].stream_buf[0];
 	float* srcs[6] = { s.px, s.py, s.pz, s.dx, s.dy, s.dz };
 	for (int k = 0; k < 3; k++) {
 		HIP_TRY(c, hipMemcpy(p_xyz + k * n, srcs[k], n * 4, hipMemcpyDeviceToHost));

@@ -78,6 +78,10 @@ typedef struct mirt_policy {
 	uint32_t max_batch;     /* accumulations kept in flight together, 0 = buckets (each lands in its own bucket) */
 	uint32_t reference_tree;/* 0 (default): traverse a GPU-internal SAH tree built over the same BVH-order prims; 1: traverse the caller's
 	                         * nodes as handed over.  Results are identical either way (DESIGN.md "Traversal semantics"); read at mirt_set_scene. */
+	uint32_t streams;       /* batches of accumulations kept in flight on separate HIP streams (0 = default 3, 1 = one kernel at a time).
+	                         * Each in-flight batch renders into its own contribution buffer; the buffers are added to the accumulator in
+	                         * accumulation order, so results do not depend on this value. */
+	uint32_t _reserved[3];
 } mirt_policy;
 
 typedef struct mirt_counters {

@@ -262,6 +262,23 @@ def test_batching_and_call_splitting_do_not_change_results(mirt):
     a.close(); b.close()
 
 
+def test_stream_pipelining_does_not_change_results(mirt):
+    """policy.streams batches run concurrently on separate HIP streams; the in-order merge of their contribution buffers
+    must reproduce the strictly sequential result bit for bit (every bucket sees its adds in accumulation order)."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    out = {}
+    for streams in (1, 2, 3, 5):
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, streams=streams); r.Resize(256, 160)
+        for n in (7, 30, 3):                                # uneven calls: partial batches, many batches in flight
+            r.AccumulateAsync(n)
+        r.Synchronize()
+        out[streams] = (r.accumulator(), r.counters()); r.close()
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(256, 160); o.Accumulate(40)
+    for streams, (acc, ctr) in out.items():
+        assert_same(acc, o.accumulator(), f"streams={streams}")
+        assert ctr["rays"] == o.counters()["rays"] and ctr["terminated"] == o.counters()["terminated"]
+
+
 def test_resume_from_loaded_accumulator(mirt):
     sc = mirt.scene.default9()
     a = mirt.Renderer(sc); a.Resize(64, 64); a.Accumulate(10)

@@ -224,7 +224,7 @@ def test_library_exports_every_declared_symbol(mirt):
 
 
 def test_struct_layouts_match_header(mirt):
-    assert C.sizeof(mirt.Policy) == 32 and C.sizeof(mirt.Counters) == 64 and C.sizeof(mirt.KernelTimes) == 80
+    assert C.sizeof(mirt.Policy) == 48 and C.sizeof(mirt.Counters) == 64 and C.sizeof(mirt.KernelTimes) == 80
     assert mirt.SPHERE.fields["radius_sq"][1] == 12 and mirt.SPHERE.fields["material_ID"][1] == 16
     assert mirt.MATERIAL.fields["emission"][1] == 36 and mirt.NODE.fields["first_id"][1] == 12 and mirt.NODE.fields["max_bound"][1] == 16
 
