@@ -345,3 +345,30 @@ def test_cpp_host_matches_python_host(mirt, tmp_path):
         img = np.frombuffer(raw[-w * hgt * 12:], dtype="<f4").reshape(hgt, w, 3)
         assert np.array_equal(img, r.GetFrame()[..., :3])
         r.close()
+
+
+@pytest.mark.parametrize("n,w,h,spp,mb", [(10000, 256, 192, 5, 9), (100000, 192, 128, 5, 9)])
+def test_large_scenes_bvh_equals_brute_force(mirt, n, w, h, spp, mb):
+    """cfg3 / cfg4 geometry (10k / 100k spheres, 9 bounce iterations): only the top of the tree fits in LDS, the rest of the
+    records and all spheres come from L2/HBM.  The BVH path must still give the brute-force accumulators bit for bit."""
+    sc = mirt.scene.synthetic(n)
+    b = mirt.Renderer(sc, max_bounces=mb, use_bvh=False); b.Resize(w, h); b.Accumulate(spp)
+    want, wc = b.accumulator(), b.counters(); b.close()
+    for reference_tree in (False, True):
+        r = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, reference_tree=reference_tree); r.Resize(w, h); r.Accumulate(spp)
+        info = r.debug_info()
+        assert info["records"] == n - 1 and 0 < info["lds_records"] < info["records"] and info["lds_spheres"] == 0
+        assert_same(r.accumulator(), want, f"S({n}) BVH (reference_tree={reference_tree}) vs brute force")
+        assert r.counters()["rays"] == wc["rays"] and r.counters()["terminated"] == wc["terminated"]
+        r.close()
+
+
+def test_cfg5_policy_16_buckets_17_bounces(mirt):
+    """BASELINE cfg5 policy (16 buckets, Policy.max_bounces 17) on S(10000) at a size the oracle's brute force finishes."""
+    sc = mirt.scene.synthetic(10000)
+    o = ob.Oracle(sc, max_bounces=17, buckets=16, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64); o.Accumulate(32)
+    r = mirt.Renderer(sc, max_bounces=17, buckets=16, use_bvh=True); r.Resize(96, 64); r.Accumulate(32)
+    assert_same(r.accumulator(), o.accumulator(), "cfg5 policy accumulator")
+    assert r.Render(); assert_same(r.GetFrame(), o.Render(), "cfg5 policy frame (even-k median)")
+    assert r.counters()["rays"] == o.counters()["rays"]
+    r.close()
