@@ -88,12 +88,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    # Rehearsal knobs (single-GPU box): MIRT_BENCH_SHARE_GPU=1 puts every rank on cuda:0, MIRT_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device); the gather then stages through host memory.  Never set by the driver.
+    backend = os.environ.get("MIRT_BENCH_BACKEND", "nccl")
+    if os.environ.get("MIRT_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm_device = "cuda" if backend == "nccl" else "cpu"
 
     def log(msg):
         if rank == 0:
@@ -134,7 +143,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = r.kernel_times(reset=True)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -142,6 +151,8 @@ def main():
     gather_ms = None
     if dist is not None:
         local = mirt.distributed.device_tensor(*r.accumulator_device(), shape=(count, cfg["buckets"], 3, 256))
+        if comm_device == "cpu":
+            local = local.cpu()
         sync_all()
         g0 = time.perf_counter()
         full = mirt.distributed.gather_accumulator(local, tiles, rank, world, cfg["buckets"])
@@ -181,7 +192,7 @@ def main():
         c = r.counters(); rays_local = c["rays"] * K // (K + W)
     rays_total = rays_local
     if dist is not None:
-        t = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        t = torch.tensor([rays_local], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rays_total = int(t.item())
 

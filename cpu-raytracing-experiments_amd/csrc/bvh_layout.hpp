@@ -94,7 +94,6 @@ inline float half_ulp_at(float magnitude) {                // spacing of binary1
 
 inline uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 24) | first; }
 
-// Returns "" on success, otherwise the reason the tree cannot be laid out.
 // 32-B half-precision records from the 64-B ones.  Returns false (and leaves `out` empty) when binary16 is not adequate:
 // a coordinate beyond +-60000, more than 65535 records (the u16 traversal stack), or a leaf box whose smallest extent is
 // under 8 quantisation steps (the box would grow by more than ~25 %).
@@ -136,6 +135,7 @@ inline bool build_half_records(const std::vector<float>& recs, std::vector<uint3
 	return true;
 }
 
+// Lays out 64-B records for `nodes`; returns "" on success, otherwise the reason the tree is rejected.
 // `prim_of_slot` (optional): leaf slot s of `nodes` refers to prims[prim_of_slot[s]] (internal tree); without it slot s is
 // prims[s] (the caller's tree, BVH.hpp:201-205).  Leaf references always carry the index into `prims` (the BVH-order
 // array hit.primID refers to); mapped leaves must hold a single prim.

@@ -93,20 +93,6 @@ MIRT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 MIRT_DI uint32_t mask_rank(unsigned long long m) {            // set bits of m below this lane
 	return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
 }
-// Stream compaction slot for lanes with `flag`: one atomicAdd per wave (call with the whole wave converged).
-MIRT_DI uint32_t wave_append(bool flag, uint32_t* counter) {
-	const unsigned long long m = __ballot(flag);
-	uint32_t base = 0;
-	if (m != 0ull) {
-		if (lane_id() == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
-		base = __builtin_amdgcn_readfirstlane(base);
-	}
-	return base + mask_rank(m);
-}
-MIRT_DI void wave_count(bool flag, unsigned long long* counter) {
-	const unsigned long long m = __ballot(flag);
-	if (m != 0ull && lane_id() == 0) atomicAdd(counter, static_cast<unsigned long long>(__popcll(m)));
-}
 MIRT_DI void wave_sum(uint32_t v, unsigned long long* counter) {
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
 	if (lane_id() == 0 && v) atomicAdd(counter, static_cast<unsigned long long>(v));

@@ -372,3 +372,35 @@ def test_cfg5_policy_16_buckets_17_bounces(mirt):
     assert r.Render(); assert_same(r.GetFrame(), o.Render(), "cfg5 policy frame (even-k median)")
     assert r.counters()["rays"] == o.counters()["rays"]
     r.close()
+
+
+def test_accumulator_device_view_for_rccl(mirt):
+    """The multi-GPU gather wraps the context's accumulator slab as a torch tensor without a copy."""
+    import torch
+    r = mirt.Renderer(mirt.scene.default9(), use_bvh=True); r.Resize(64, 48); r.Accumulate(5)
+    ptr, nbytes = r.accumulator_device()
+    t = mirt.distributed.device_tensor(ptr, nbytes, shape=(12, 5, 3, 256))
+    assert t.is_cuda and t.dtype == torch.float32 and t.data_ptr() == ptr
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), r.accumulator().view(np.uint32))
+    assert mirt.distributed.gather_accumulator(t, 12, 0, 1, 5) is t
+    r.close()
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's torch.distributed path (env parsing, tile sharding, barriers, MAX/SUM reductions, gather) with two ranks
+    sharing this box's single GPU over gloo; on the 8-GPU node the driver runs the same code over RCCL."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MIRT_BENCH_SHARE_GPU="1", MIRT_BENCH_BACKEND="gloo")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "5", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["image"] == "2048x1024" and d["gather_ms"] is not None
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["rays_per_step"] > 2 * 9e6
