@@ -200,6 +200,39 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+// Select-only forms of the two sphere tests for the traversal loop (same arithmetic and acceptance as sphere_closest /
+// sphere_occludes above; a divergent branch costs several scalar exec-mask instructions, and the CU's single scalar unit
+// was issuing as many instructions as its four SIMDs).
+MIRT_DI void sphere_closest_sel(bool lane_on, float4 s, int32_t prim, const float px, const float py, const float pz, const float dx, const float dy,
+                                const float dz, float& tfar, int32_t& primID) {
+	const float tx = s.x - px;
+	float b = dx * tx;
+	float disc = __builtin_fmaf(-tx, tx, s.w);
+	const float ty = s.y - py;
+	b = __builtin_fmaf(dy, ty, b);
+	disc = __builtin_fmaf(-ty, ty, disc);
+	const float tz = s.z - pz;
+	b = __builtin_fmaf(dz, tz, b);
+	disc = __builtin_fmaf(-tz, tz, disc);
+	disc = __builtin_fmaf(b, b, disc);
+	const bool disc_ok = !(__float_as_uint(disc) & 0x80000000u);
+	const float sq = __builtin_sqrtf(disc);                       // NaN for a negative discriminant: masked by disc_ok
+	float dist = b - sq;
+	dist = (__float_as_uint(dist) & 0x80000000u) ? b + sq : dist;
+	const bool cand = lane_on && disc_ok && (dist < MIRT_FLT_MAX) && !(__float_as_uint(dist) & 0x80000000u);
+	const bool better = cand && (dist < tfar || (dist == tfar && (primID < 0 || prim < primID)));
+	tfar = better ? dist : tfar;
+	primID = better ? prim : primID;
+}
+MIRT_DI bool sphere_occludes_sel(float4 s, const float px, const float py, const float pz, const float dx, const float dy, const float dz, const float tfar) {
+	const f3 P{ s.x - px, s.y - py, s.z - pz };
+	const float b = dot3(f3{ dx, dy, dz }, P);
+	const float disc = b * b - dot3(P, P) + s.w;
+	const float sq = __builtin_sqrtf(disc);
+	const float dist = (b >= sq ? b - sq : b + sq);
+	return !(disc < 0.0f) && !(dist < 0.0f || dist >= tfar);
+}
+
 struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] entries (u32, or u16 with half records)
 MIRT_DI float half_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(w & 0xffffu))); }
 MIRT_DI float half_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(w >> 16))); }
@@ -264,51 +297,63 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	bool hb = slab_hit(__builtin_fmaf(bx0, rs.ix, rs.nx), __builtin_fmaf(bx1, rs.ix, rs.nx),
 	                   __builtin_fmaf(by0, rs.iy, rs.ny), __builtin_fmaf(by1, rs.iy, rs.ny),
 	                   __builtin_fmaf(bz0, rs.iz, rs.nz), __builtin_fmaf(bz1, rs.iz, rs.nz), t.tfar, tb);
-	// Hit leaf children are intersected at once, child 0 before child 1.  ONE instance of the sphere code serves both:
-	// each lane queues its first hit leaf in l0 (and, rarely, a second one in l1) and the wave loops while any lane has
-	// one queued — an unrolled copy per child ran ~90 sphere-test instructions on almost every step for ~5 % of the lanes.
-	{
-		const bool la = ha && (c0 & kLeafBit), lb = hb && (c1 & kLeafBit);
-		uint32_t l0 = la ? c0 : (lb ? c1 : 0u);
-		uint32_t l1 = (la && lb) ? c1 : 0u;
-		while (__ballot(l0 != 0u) != 0ull) {
-			if (l0 != 0u) {
-				const uint32_t first = l0 & 0xffffffu, count = ((l0 >> 24) & 0x7fu) + 1u;
-				for (uint32_t p = first; p < first + count; p++) {
+
+	// ---- hit leaf children are intersected at once, child 0 before child 1 (same per-ray order as the oracle's twin) ----
+	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
+	const bool la = ha && leaf_a, lb = hb && leaf_b;
+	if (__ballot(la || lb) != 0ull) {                              // wave-uniform guard: scalar branch, no exec-mask bookkeeping
+		// first queued leaf of this lane = child 0 if it is a hit leaf, else child 1; a second one only when both are
+		uint32_t l0 = la ? c0 : c1;
+		bool on = la || lb;
+		bool second = la && lb;
+		for (int pass = 0; pass < 2; pass++) {
+			if (pass == 1 && __ballot(second) == 0ull) break;
+			if (pass == 1) { l0 = c1; on = second; }
+			const uint32_t first = l0 & 0xffffffu;
+			const uint32_t idx = on ? first : 0u;                   // idle lanes read sphere 0 (always valid: a leaf exists)
+			float4 s;
+			if (ALL_LDS || idx < sc.lds_spheres) s = to_float4(lds.spheres[idx]); else s = sc.spheres[idx];
+			if (COUNT) n_spheres += on ? 1u : 0u;
+			if (ANYHIT) occluded = occluded || (on && sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
+			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
+			// leaves with more than one prim (never produced by the builders here; accepted from callers): remaining prims, rare path
+			const uint32_t extra = on ? ((l0 >> 24) & 0x7fu) : 0u;
+			if (__ballot(extra != 0u) != 0ull) {
+				for (uint32_t k = 1; k <= extra; k++) {
+					const uint32_t p = first + k;
 					if (COUNT) n_spheres++;
-					float4 s;
-					if (ALL_LDS || p < sc.lds_spheres) s = to_float4(lds.spheres[p]); else s = sc.spheres[p];
-					if (ANYHIT) { if (sphere_occludes(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar)) { occluded = true; break; } }
-					else sphere_closest_tie(s, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
+					float4 s2;
+					if (ALL_LDS || p < sc.lds_spheres) s2 = to_float4(lds.spheres[p]); else s2 = sc.spheres[p];
+					if (ANYHIT) occluded = occluded || sphere_occludes_sel(s2, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar);
+					else sphere_closest_sel(true, s2, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 				}
 			}
-			l0 = (ANYHIT && occluded) ? 0u : l1;
-			l1 = 0u;
 		}
-		if (ANYHIT && occluded) return true;
 	}
-	ha = ha && !(c0 & kLeafBit); hb = hb && !(c1 & kLeafBit);
+	// ---- next node: selects, plus one exec region each for the conditional stack write and read ----
+	ha = ha && !leaf_a; hb = hb && !leaf_b;
 	if (!ANYHIT) { ha = ha && ta <= t.tfar; hb = hb && tb <= t.tfar; }          // re-check against the shrunken tfar
-	if (ha && hb) {
-		const bool a_first = ANYHIT ? true : (ta <= tb);
-		const uint32_t far = a_first ? c1 : c0;                                // inner reference = record index; depth < 64 is validated on the host
-		if (t.sp < kLdsStack) {
-			if (HALF) ((lds_u16*)lds.stack)[t.sp * lstride + threadIdx.x] = static_cast<uint16_t>(far);
-			else lds.stack[t.sp * lstride + threadIdx.x] = far;
-		} else if (t.sp < kStack) spill.e[t.sp - kLdsStack] = far;
-		t.sp++;
-		t.cur = a_first ? c0 : c1;
-		return false;
+	const bool both = ha && hb, none = !(ha || hb);
+	const bool a_first = ANYHIT ? true : (ta <= tb);
+	const uint32_t near = (ha && (a_first || !hb)) ? c0 : c1;                 // the child entered when at least one inner child is hit
+	const uint32_t far = a_first ? c1 : c0;                                   // inner reference = record index; depth < 64 is validated on the host
+	uint32_t sp = t.sp;
+	if (both) {
+		if (sp < kLdsStack) { if (HALF) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(far); else lds.stack[sp * lstride + threadIdx.x] = far; }
+		else if (sp < kStack) spill.e[sp - kLdsStack] = far;
 	}
-	if (ha) { t.cur = c0; return false; }
-	if (hb) { t.cur = c1; return false; }
-	if (t.sp == 0) return true;
-	--t.sp;
-	if (t.sp < kLdsStack) {
-		if (HALF) t.cur = ((lds_u16*)lds.stack)[t.sp * lstride + threadIdx.x];
-		else t.cur = lds.stack[t.sp * lstride + threadIdx.x];
-	} else t.cur = spill.e[t.sp - kLdsStack];
-	return false;
+	sp += both ? 1u : 0u;
+	uint32_t next = near;
+	const bool pop = none && sp != 0u;
+	if (pop) {
+		--sp;
+		if (sp < kLdsStack) next = HALF ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
+		else next = spill.e[sp - kLdsStack];
+	}
+	const bool finished = (ANYHIT && occluded) || (none && !pop);
+	t.sp = sp;
+	t.cur = next;
+	return finished;
 }
 
 // ---- persistent waves with in-kernel lane refill ------------------------------------------------------------
