@@ -219,8 +219,9 @@ MIRT_DI void sphere_closest_sel(bool lane_on, float4 s, int32_t prim, const floa
 	const float sq = __builtin_sqrtf(disc);                       // NaN for a negative discriminant: masked by disc_ok
 	float dist = b - sq;
 	dist = (__float_as_uint(dist) & 0x80000000u) ? b + sq : dist;
-	const bool cand = lane_on && disc_ok && (dist < MIRT_FLT_MAX) && !(__float_as_uint(dist) & 0x80000000u);
-	const bool better = cand && (dist < tfar || (dist == tfar && (primID < 0 || prim < primID)));
+	// bitwise &,| on purpose: short-circuit &&,|| come back as nested exec-mask branches
+	const bool cand = lane_on & disc_ok & (dist < MIRT_FLT_MAX) & !(__float_as_uint(dist) & 0x80000000u);
+	const bool better = cand & ((dist < tfar) | ((dist == tfar) & ((primID < 0) | (prim < primID))));
 	tfar = better ? dist : tfar;
 	primID = better ? prim : primID;
 }
@@ -230,7 +231,7 @@ MIRT_DI bool sphere_occludes_sel(float4 s, const float px, const float py, const
 	const float disc = b * b - dot3(P, P) + s.w;
 	const float sq = __builtin_sqrtf(disc);
 	const float dist = (b >= sq ? b - sq : b + sq);
-	return !(disc < 0.0f) && !(dist < 0.0f || dist >= tfar);
+	return !(disc < 0.0f) & !((dist < 0.0f) | (dist >= tfar));
 }
 
 struct TraceLds { const lds_v4f* recs; const lds_v4f* spheres; lds_u32* stack; };   // stack: [kLdsStack][blockDim.x] entries (u32, or u16 with half records)
@@ -300,12 +301,12 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 
 	// ---- hit leaf children are intersected at once, child 0 before child 1 (same per-ray order as the oracle's twin) ----
 	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
-	const bool la = ha && leaf_a, lb = hb && leaf_b;
-	if (__ballot(la || lb) != 0ull) {                              // wave-uniform guard: scalar branch, no exec-mask bookkeeping
+	const bool la = ha & leaf_a, lb = hb & leaf_b;
+	if (__ballot(la | lb) != 0ull) {                              // wave-uniform guard: scalar branch, no exec-mask bookkeeping
 		// first queued leaf of this lane = child 0 if it is a hit leaf, else child 1; a second one only when both are
 		uint32_t l0 = la ? c0 : c1;
-		bool on = la || lb;
-		bool second = la && lb;
+		bool on = la | lb;
+		bool second = la & lb;
 		for (int pass = 0; pass < 2; pass++) {
 			if (pass == 1 && __ballot(second) == 0ull) break;
 			if (pass == 1) { l0 = c1; on = second; }
@@ -314,7 +315,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			float4 s;
 			if (ALL_LDS || idx < sc.lds_spheres) s = to_float4(lds.spheres[idx]); else s = sc.spheres[idx];
 			if (COUNT) n_spheres += on ? 1u : 0u;
-			if (ANYHIT) occluded = occluded || (on && sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
+			if (ANYHIT) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
 			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 			// leaves with more than one prim (never produced by the builders here; accepted from callers): remaining prims, rare path
 			const uint32_t extra = on ? ((l0 >> 24) & 0x7fu) : 0u;
@@ -331,11 +332,11 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		}
 	}
 	// ---- next node: selects, plus one exec region each for the conditional stack write and read ----
-	ha = ha && !leaf_a; hb = hb && !leaf_b;
-	if (!ANYHIT) { ha = ha && ta <= t.tfar; hb = hb && tb <= t.tfar; }          // re-check against the shrunken tfar
-	const bool both = ha && hb, none = !(ha || hb);
+	ha = ha & !leaf_a; hb = hb & !leaf_b;
+	if (!ANYHIT) { ha = ha & (ta <= t.tfar); hb = hb & (tb <= t.tfar); }        // re-check against the shrunken tfar
+	const bool both = ha & hb, none = !(ha | hb);
 	const bool a_first = ANYHIT ? true : (ta <= tb);
-	const uint32_t near = (ha && (a_first || !hb)) ? c0 : c1;                 // the child entered when at least one inner child is hit
+	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one inner child is hit
 	const uint32_t far = a_first ? c1 : c0;                                   // inner reference = record index; depth < 64 is validated on the host
 	uint32_t sp = t.sp;
 	if (both) {
@@ -344,13 +345,13 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	}
 	sp += both ? 1u : 0u;
 	uint32_t next = near;
-	const bool pop = none && sp != 0u;
+	const bool pop = none & (sp != 0u);
 	if (pop) {
 		--sp;
 		if (sp < kLdsStack) next = HALF ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
 		else next = spill.e[sp - kLdsStack];
 	}
-	const bool finished = (ANYHIT && occluded) || (none && !pop);
+	const bool finished = (ANYHIT & occluded) | (none & !pop);
 	t.sp = sp;
 	t.cur = next;
 	return finished;
