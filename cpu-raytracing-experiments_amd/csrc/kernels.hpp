@@ -165,16 +165,34 @@ MIRT_DI bool sphere_occludes(float4 s, float px, float py, float pz, float dx, f
 // [0, tfar], and the closest hit is the lexicographic minimum of (dist, BVH-order prim index) — which is
 // what the ascending strict-'<' scan of intersect_prims returns — so visiting order, pruning and the slab
 // arithmetic cannot change the result.  oracle/oracle.cpp mode 2 is the CPU twin of this routine.
-struct RaySlab { float ix, iy, iz, nx, ny, nz; };
+// Conservative "cone" slab test.  The reference's sphere tests assume a unit direction (disc = b^2 - |oc|^2 + r^2,
+// BVH.hpp:251-260,295-296), but its tangent frame is ill-conditioned near N.z = -1 (Sampling.hpp:150-159) and to_world can
+// return a stretched direction (|D| = 1.125 seen in cfg2); for such a ray a sphere it geometrically misses can still pass
+// the reference's test, by a margin that grows with distance — no fixed box padding covers that.  Algebra: with d the
+// reported hit parameter, |p + d*D - c|^2 = r^2 + d^2 (|D|^2 - 1) (+ rounding of the f32 sphere arithmetic, <= 2^-19 d^2),
+// so the reported hit point lies within alpha*d of the sphere, alpha^2 = max(|D|^2-1, 0) + 2^-19.  The boxes are therefore
+// tested against the ray inflated by alpha*t (L-inf) at parameter t:
+//     lo_i - alpha t <= p_i + t d_i <= hi_i + alpha t   <=>   t (d_i+alpha) >= lo_i - p_i   and   t (d_i-alpha) <= hi_i - p_i
+// i.e. the usual slab test with reciprocal 1/(d_i+alpha) for the lo plane and 1/(d_i-alpha) for the hi plane (still one FMA
+// per plane).  An axis with |d_i| <= alpha yields two lower bounds and is dropped (lo -> -inf, hi -> +inf), which also
+// covers zero direction components.  For unit directions alpha = 1.4e-3: +4 % box tests on S(1000).
+struct RaySlab { float iax, iay, iaz, nax, nay, naz, ibx, iby, ibz, nbx, nby, nbz; };
+MIRT_DI void slab_axis(float p, float d, float alpha, float& ia, float& na, float& ib, float& nb) {
+	const bool keep = fabs_bits(d) > alpha;
+	const float r = 1.0f / ((d - alpha) * (d + alpha));         // one division per axis: 1/(d+a) = (d-a)/(d^2-a^2), 1/(d-a) = (d+a)/(d^2-a^2)
+	const float ra = (d - alpha) * r, rb = (d + alpha) * r;
+	ia = keep ? ra : 0.0f; ib = keep ? rb : 0.0f;
+	na = keep ? -(p * ra) : -__builtin_inff();
+	nb = keep ? -(p * rb) : __builtin_inff();
+}
 MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
-	// A zero (or denormal-small) direction component would make inv infinite and fma(plane, inf, -p*inf) = inf - inf = NaN.
-	// The box test only has to stay conservative, so such components get a huge finite reciprocal instead: the slab
-	// values keep the right sign and dwarf every finite t of the other axes.
+	const float L2 = (dx * dx + dy * dy) + dz * dz;
+	const float a2 = __builtin_fmaxf(L2 - 1.0f, 0.0f) * 1.0009765625f + 0x1p-19f;
+	const float alpha = __builtin_sqrtf(a2) * 1.0009765625f;
 	RaySlab s;
-	s.ix = (fabs_bits(dx) < 1e-30f) ? copysign_bits(1e30f, dx) : 1.0f / dx;
-	s.iy = (fabs_bits(dy) < 1e-30f) ? copysign_bits(1e30f, dy) : 1.0f / dy;
-	s.iz = (fabs_bits(dz) < 1e-30f) ? copysign_bits(1e30f, dz) : 1.0f / dz;
-	s.nx = -(px * s.ix); s.ny = -(py * s.iy); s.nz = -(pz * s.iz);
+	slab_axis(px, dx, alpha, s.iax, s.nax, s.ibx, s.nbx);
+	slab_axis(py, dy, alpha, s.iay, s.nay, s.iby, s.nby);
+	slab_axis(pz, dz, alpha, s.iaz, s.naz, s.ibz, s.nbz);
 	return s;
 }
 // fminf/fmaxf lower to v_min_f32 / v_max_f32 (v_min3/v_max3): NaNs from 0*inf slabs are dropped.
@@ -292,12 +310,12 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	if (COUNT) n_nodes += 2;
 	const RaySlab& rs = t.rs;
 	float ta, tb;
-	bool ha = slab_hit(__builtin_fmaf(ax0, rs.ix, rs.nx), __builtin_fmaf(ax1, rs.ix, rs.nx),
-	                   __builtin_fmaf(ay0, rs.iy, rs.ny), __builtin_fmaf(ay1, rs.iy, rs.ny),
-	                   __builtin_fmaf(az0, rs.iz, rs.nz), __builtin_fmaf(az1, rs.iz, rs.nz), t.tfar, ta);
-	bool hb = slab_hit(__builtin_fmaf(bx0, rs.ix, rs.nx), __builtin_fmaf(bx1, rs.ix, rs.nx),
-	                   __builtin_fmaf(by0, rs.iy, rs.ny), __builtin_fmaf(by1, rs.iy, rs.ny),
-	                   __builtin_fmaf(bz0, rs.iz, rs.nz), __builtin_fmaf(bz1, rs.iz, rs.nz), t.tfar, tb);
+	bool ha = slab_hit(__builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
+	                   __builtin_fmaf(ay0, rs.iay, rs.nay), __builtin_fmaf(ay1, rs.iby, rs.nby),
+	                   __builtin_fmaf(az0, rs.iaz, rs.naz), __builtin_fmaf(az1, rs.ibz, rs.nbz), t.tfar, ta);
+	bool hb = slab_hit(__builtin_fmaf(bx0, rs.iax, rs.nax), __builtin_fmaf(bx1, rs.ibx, rs.nbx),
+	                   __builtin_fmaf(by0, rs.iay, rs.nay), __builtin_fmaf(by1, rs.iby, rs.nby),
+	                   __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
 
 	// ---- hit leaf children are intersected at once, child 0 before child 1 (same per-ray order as the oracle's twin) ----
 	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
@@ -397,30 +415,33 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_
 
 // Persistent wave loop shared by the closest-hit and the any-hit kernels.
 //   * a lane is RUNNING (ri != kNone, !done), DONE (result waiting to be flushed) or EMPTY;
-//   * each lane also holds one PREFETCHED ray (nri + origin/direction[/tfar] in registers) whose loads were issued at the
-//     previous refill event, so switching to it costs no memory wait;
-//   * a refill event (>= kRefillIdle lanes not running) flushes results, switches idle lanes to their prefetched ray,
-//     hands out new indices and issues the loads for the next prefetch — all as batched, mostly coalesced accesses.
+//   * a refill event (>= kRefillIdle lanes not running) flushes the finished lanes' results, hands the idle lanes the next
+//     ray indices of the window and loads + sets up their rays — all as batched, mostly coalesced accesses.  (An earlier
+//     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
+//     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
 template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
 	WaveWindow w{ 0, 0, pick_chunk(n), true };
 	Trav t;
 	TravSpill spill;
-	uint32_t ri = kNone, nri = kNone;
+	uint32_t ri = kNone;
 	bool done = false, occluded = false;
-	float npx = 0, npy = 0, npz = 0, ndx = 1, ndy = 1, ndz = 1, ntf = 0;
 	for (;;) {
-		// ---- refill event ----
+		// ---- refill event: flush results, hand the idle lanes the next ray indices of the window, load and set up their rays ----
 		if (done) { store_result(ri, t, occluded); done = false; ri = kNone; }
-		if (ri == kNone && nri != kNone) { ri = nri; nri = kNone; occluded = false; trav_begin(t, npx, npy, npz, ndx, ndy, ndz, ntf); }
 		{
-			const uint32_t got = wave_take(nri == kNone, w, n, work_next);
-			if (got != kNone) { nri = got; load_ray(got, npx, npy, npz, ndx, ndy, ndz, ntf); }
+			const uint32_t got = wave_take(ri == kNone, w, n, work_next);
+			if (got != kNone) {
+				float px, py, pz, dx, dy, dz, tf;
+				load_ray(got, px, py, pz, dx, dy, dz, tf);
+				ri = got; occluded = false;
+				trav_begin(t, px, py, pz, dx, dy, dz, tf);
+			}
 		}
 		const bool work_left = w.more || w.beg != w.end;
-		if (__ballot(ri != kNone) == 0ull) { if (__ballot(nri != kNone) == 0ull && !work_left) break; continue; }
-		const bool can_refill = work_left || __ballot(nri != kNone) != 0ull;
+		if (__ballot(ri != kNone) == 0ull) { if (!work_left) break; continue; }
+		const bool can_refill = work_left;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
 		for (;;) {
 			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS, HALF>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
@@ -522,6 +543,7 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint
 // launch ends with a tail while its longest rays finish (~180 us at 16k+ rays, measured), so draining both in one
 // persistent kernel halves the number of tails: a wave that runs out of closest-hit rays moves on to the shadow queue.
 // Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
+// 8 waves/SIMD (= two 16-wave workgroups per CU, the LDS plan of the binary16 layout) caps the kernel at 64 VGPRs.
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,

@@ -682,20 +682,37 @@ static void bvh_quantize_half(BVH& bvh) {
 		b.mx[a] = _cvtsh_ss(_cvtss_sh(b.mx[a], _MM_FROUND_TO_POS_INF | _MM_FROUND_NO_EXC));
 	}
 }
-struct RaySlab { float ix, iy, iz, nx, ny, nz; };
+// Conservative "cone" slab test.  The reference's sphere tests assume a unit direction (disc = b^2 - |oc|^2 + r^2,
+// BVH.hpp:251-260,295-296), but its tangent frame is ill-conditioned near N.z = -1 (Sampling.hpp:150-159) and can hand
+// back stretched directions; for such a ray a sphere the ray geometrically misses can still pass the test.  Algebra:
+// with d the reported hit parameter, |p + d*D - c|^2 = r^2 + d^2 (|D|^2 - 1) (+ rounding), i.e. the reported hit point
+// lies within d*sqrt(|D|^2-1) of the sphere.  So the boxes are tested against the ray inflated by alpha*t (L-inf) at
+// parameter t, alpha^2 = max(|D|^2-1,0)*(1+2^-10) + g_cone_fuzz (rounding of the sphere arithmetic, relative to distance):
+//     lo_i - alpha t <= p_i + t d_i <= hi_i + alpha t   <=>   t (d_i+alpha) >= lo_i - p_i  and  t (d_i-alpha) <= hi_i - p_i
+// which is the usual slab test with reciprocal 1/(d_i+alpha) for the lo plane and 1/(d_i-alpha) for the hi plane; an
+// axis with |d_i| <= alpha gives two lower bounds and is dropped (lo -> -inf, hi -> +inf).
+static float g_cone_fuzz = 0x1p-19f;
+struct RaySlab { float ia[3], na[3], ib[3], nb[3]; };
 static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
-	RaySlab s;      // zero / denormal-small components get a huge finite reciprocal (see make_slab in csrc/kernels.hpp)
-	s.ix = (fast_abs(dx) < 1e-30f) ? fast_copysign(1e30f, dx) : 1.0f / dx;
-	s.iy = (fast_abs(dy) < 1e-30f) ? fast_copysign(1e30f, dy) : 1.0f / dy;
-	s.iz = (fast_abs(dz) < 1e-30f) ? fast_copysign(1e30f, dz) : 1.0f / dz;
-	s.nx = -(px * s.ix); s.ny = -(py * s.iy); s.nz = -(pz * s.iz);
+	RaySlab s;
+	const float L2 = (dx * dx + dy * dy) + dz * dz;
+	const float a2 = fmaxf(L2 - 1.0f, 0.0f) * 1.0009765625f + g_cone_fuzz;
+	const float alpha = sqrtf(a2) * 1.0009765625f;
+	const float p[3] = { px, py, pz }, d[3] = { dx, dy, dz };
+	for (int a = 0; a < 3; a++) {
+		if (!(fast_abs(d[a]) > alpha)) { s.ia[a] = 0.0f; s.ib[a] = 0.0f; s.na[a] = -INFINITY; s.nb[a] = INFINITY; }
+		else {
+			const float r = 1.0f / ((d[a] - alpha) * (d[a] + alpha));      // as slab_axis() in csrc/kernels.hpp
+			s.ia[a] = (d[a] - alpha) * r; s.ib[a] = (d[a] + alpha) * r; s.na[a] = -(p[a] * s.ia[a]); s.nb[a] = -(p[a] * s.ib[a]);
+		}
+	}
 	return s;
 }
-// slab test on [0, tfar]; fminf/fmaxf drop NaNs (0 * inf) exactly like v_min_f32 / v_max_f32
+// slab test on [0, tfar]; fminf/fmaxf drop NaNs exactly like v_min_f32 / v_max_f32
 static inline bool slab_test(const RaySlab& s, const Box& b, float tfar, float* tnear) {
-	const float lx = fmaf(b.mn[0], s.ix, s.nx), hx = fmaf(b.mx[0], s.ix, s.nx);
-	const float ly = fmaf(b.mn[1], s.iy, s.ny), hy = fmaf(b.mx[1], s.iy, s.ny);
-	const float lz = fmaf(b.mn[2], s.iz, s.nz), hz = fmaf(b.mx[2], s.iz, s.nz);
+	const float lx = fmaf(b.mn[0], s.ia[0], s.na[0]), hx = fmaf(b.mx[0], s.ib[0], s.nb[0]);
+	const float ly = fmaf(b.mn[1], s.ia[1], s.na[1]), hy = fmaf(b.mx[1], s.ib[1], s.nb[1]);
+	const float lz = fmaf(b.mn[2], s.ia[2], s.na[2]), hz = fmaf(b.mx[2], s.ib[2], s.nb[2]);
 	const float tmin = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.0f));
 	const float tmax = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tfar));
 	*tnear = tmin;
@@ -810,7 +827,16 @@ struct Oracle {
 	Counters counters;
 };
 
-static void traverse(const Oracle& o, const Buffer& in, Hit& out, size_t size, LocalCounters& lc) {         // BVH.hpp:309-360
+// experiment: histogram of |D|^2 - 1 over all rays handed to traverse() (orc_len_hist)
+static std::atomic<uint64_t> g_len_hist[16];
+static bool g_len_hist_on = false;
+static void traverse(const Oracle& o, const Buffer& in, Hit& out, size_t size, LocalCounters& lc) {
+	if (g_len_hist_on) for (size_t i = 0; i < size; i++) {
+		const float L2 = (in.dir.x[i] * in.dir.x[i] + in.dir.y[i] * in.dir.y[i]) + in.dir.z[i] * in.dir.z[i];
+		const float e = fabsf(L2 - 1.0f);
+		int b = 0; float th = 1e-7f; while (b < 15 && e > th) { th *= 3.1622776f; b++; }
+		g_len_hist[b * 1 + 0]++;
+	}         // BVH.hpp:309-360
 	lc.rays += size;
 	if (o.trav_mode == 0) {
 		intersect_prims(o.bvh, in, out, 0, size, 0, o.bvh.prims.size(), lc);
@@ -846,6 +872,10 @@ static size_t sort_rayID(uint32_t k, uint32_t count, uint32_t* out, const int32_
 	for (int32_t i = static_cast<int32_t>(count) - 1; i >= 0; i--) out[--sort_buffer[key[i] + 1]] = static_cast<uint32_t>(i);
 	return ret;
 }
+
+// Debug hook (orc_debug_path): records, for one pixel of one tile, the ray and its hit at every bounce.
+struct PathDebug { bool on = false; uint32_t px = 0; int n = 0; float rec[64][8]; };
+static thread_local PathDebug g_dbg;
 
 // Renderer.hpp:83-432 — one tile, one Accumulate() call
 static void accumulate_tile(const Oracle& o, uint32_t LaunchIndex, uint32_t accumulations, float* accumulator, LocalCounters& lc) {
@@ -892,6 +922,11 @@ static void accumulate_tile(const Oracle& o, uint32_t LaunchIndex, uint32_t accu
 			ray_stream.hit.tfar[i] = FLT_MAX; ray_stream.hit.matID[i] = -1; ray_stream.hit.primID[i] = -1;
 		}
 		traverse(o, *in, ray_stream.hit, active_rays, lc);                      // :165
+		if (g_dbg.on) for (size_t ID = 0; ID < active_rays; ID++) if (in->pixelID[ID] == g_dbg.px && g_dbg.n < 64) {
+			float* r = g_dbg.rec[g_dbg.n++];
+			r[0] = in->p.x[ID]; r[1] = in->p.y[ID]; r[2] = in->p.z[ID]; r[3] = in->dir.x[ID]; r[4] = in->dir.y[ID]; r[5] = in->dir.z[ID];
+			r[6] = ray_stream.hit.tfar[ID]; r[7] = static_cast<float>(ray_stream.hit.primID[ID]);
+		}
 
 		for (size_t ID = 0; ID < active_rays; ID++) {                           // :169-214 closest-hit shader
 			const int32_t mat_ID = ray_stream.hit.matID[ID];
@@ -1152,6 +1187,8 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	}
 	return 0;
 }
+void orc_len_hist(int on, uint64_t* out) { g_len_hist_on = on != 0; if (out) for (int i = 0; i < 16; i++) out[i] = g_len_hist[i]; }
+void orc_set_cone_fuzz(float f) { g_cone_fuzz = f; }
 void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.accel, o.bvh.prims, pad_rel); if (o.accel_half) bvh_quantize_half(o.accel); }
 // internal_tree: 1 = internal SAH tree (product default), 0 = the reference tree; half: binary16 boxes (product's 32-B records)
 void orc_set_mode2_tree(void* h, int internal_tree, int half) { Oracle& o = *static_cast<Oracle*>(h); o.accel_internal = internal_tree != 0; o.accel_half = half != 0; build_accel(o); }
@@ -1241,6 +1278,18 @@ void orc_trace_shadow(void* h, int trav_mode, size_t n, const float* p_xyz, cons
 		else if (!o.accel.nodes.empty()) occ = traverse_ray_shadow(o.accel, o.bvh.prims, px, py, pz, dx, dy, dz, tfar[i], lc);
 		occluded[i] = occ ? 1 : 0;
 	}
+}
+
+// Path of one pixel (tile LaunchIndex, pixel px) in Accumulate() number `accumulations`: out[b*8..] = p, dir, tfar, primID per bounce.
+int orc_debug_path(void* h, uint32_t LaunchIndex, uint32_t px, uint32_t accumulations, float* out) {
+	Oracle& o = *static_cast<Oracle*>(h);
+	std::vector<float> scratch(o.accumulator.size(), 0.0f);
+	LocalCounters lc;
+	g_dbg.on = true; g_dbg.px = px; g_dbg.n = 0;
+	accumulate_tile(o, LaunchIndex, accumulations, scratch.data(), lc);
+	g_dbg.on = false;
+	memcpy(out, g_dbg.rec, sizeof(float) * 8 * g_dbg.n);
+	return g_dbg.n;
 }
 
 // ---- unit functions (KATs / per-function fixtures) -------------------------------------

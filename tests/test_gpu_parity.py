@@ -404,3 +404,24 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["image"] == "2048x1024" and d["gather_ms"] is not None
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["rays_per_step"] > 2 * 9e6
+
+
+def test_cfg2_full_size_properties(mirt):
+    """BASELINE cfg2 at full size (1024x1024, 64 accumulations, S(1000), 5 bounce iterations; 132 M closest-hit rays):
+    the shipped configuration (internal SAH tree, binary16 records, 3 batches in flight) must reproduce the brute-force
+    path's accumulators bit for bit; every path is accounted for; Render() gates on accumulations % 5."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    fast = mirt.Renderer(sc, max_bounces=5, use_bvh=True); fast.Resize(1024, 1024); fast.AccumulateAsync(64)
+    slow = mirt.Renderer(sc, max_bounces=5, use_bvh=False, streams=1); slow.Resize(1024, 1024); slow.Accumulate(64)
+    fast.Synchronize()
+    cf, cs = fast.counters(), slow.counters()
+    assert cf["rays"] == cs["rays"] > 130_000_000 and cf["shadow_rays"] == cs["shadow_rays"]
+    assert cf["terminated"] + cf["dropped"] == 64 * 1024 * 1024 == cs["terminated"] + cs["dropped"]
+    assert_same(fast.accumulator(), slow.accumulator(), "cfg2 full size: BVH pipeline vs brute force")
+    assert not fast.Render()                              # 64 % 5 != 0
+    fast.Accumulate(1); slow.Accumulate(1)
+    assert fast.Render() and slow.Render()
+    assert_same(fast.GetFrame(), slow.GetFrame(), "cfg2 full size frame")
+    acc = fast.accumulator()
+    assert np.isfinite(acc).all() and (acc >= 0).all()
+    fast.close(); slow.close()
