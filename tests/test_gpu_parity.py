@@ -425,3 +425,35 @@ def test_cfg2_full_size_properties(mirt):
     acc = fast.accumulator()
     assert np.isfinite(acc).all() and (acc >= 0).all()
     fast.close(); slow.close()
+
+
+def test_edit_protocol_scene_and_camera_changes(mirt):
+    """The reference's edit loop (Application.cpp:299-333, 508-510): change the scene or the camera, rebuild BVH + light
+    list, ResetAccumulator, keep accumulating.  After each edit the result must equal a fresh render of the edited scene."""
+    sc = mirt.scene.synthetic(200, ambient=0.5)
+    r = mirt.Renderer(sc, max_bounces=6, use_bvh=True); r.Resize(96, 64); r.Accumulate(7)
+    # geometry + material edit
+    sc.geometry["position"][17] += np.float32([0.5, 0.25, -0.75]); sc.geometry["radius_sq"][33] *= np.float32(2.0)
+    sc.geometry["material_ID"][40] = 16                                   # becomes a light -> light list changes
+    sc.material["albedo"][3] = np.float32([0.9, 0.1, 0.2])
+    r.UpdateScene(); r.ResetAccumulator(); r.Accumulate(10)
+    o = ob.Oracle(sc, max_bounces=6, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64); o.Accumulate(10)
+    assert np.array_equal(r.lights, o.lights()) and len(r.lights) == 200 // 64 + 1
+    assert_same(r.accumulator(), o.accumulator(), "after scene edit")
+    # camera move (View::Translate / Rotate results are host-side; the path only sees pos + orient)
+    sc.camera.pos = sc.camera.pos + np.float32([1.0, -0.5, 2.0])
+    sc.camera.orient = mirt.scene.quat_look_at(mirt.scene._normalize((0.2, -0.4, -1.0)))
+    r.UpdateCamera(); r.ResetAccumulator(); r.Accumulate(5)
+    o.update_camera(); o.ResetAccumulator(); o.Accumulate(5)
+    assert_same(r.accumulator(), o.accumulator(), "after camera move")
+    assert r.Render(); assert_same(r.GetFrame(), o.Render(), "frame after camera move")
+    # resize keeps the scene, resets the accumulation
+    r.Resize(64, 96); o.Resize(64, 96); r.Accumulate(5); o.Accumulate(5)
+    assert r.accumulations == 5
+    assert_same(r.accumulator(), o.accumulator(), "after resize")
+    # policy change of the bucket count reallocates and resets
+    r.set_policy(buckets=3); r.Accumulate(6)
+    o3 = ob.Oracle(sc, max_bounces=6, buckets=3, trav_mode=ob.TRAV_BRUTE); o3.Resize(64, 96); o3.Accumulate(6)
+    assert_same(r.accumulator(), o3.accumulator(), "after bucket-count change"); assert r.Render()
+    assert_same(r.GetFrame(), o3.Render(), "3-bucket median frame")
+    r.close()
