@@ -15,8 +15,13 @@ def pytest_configure(config):
 
 
 def load_mirt():
-    """The package directory name has hyphens, so it is imported through importlib."""
-    return importlib.import_module("cpu-raytracing-experiments_amd")
+    """The package directory name has hyphens, so it is imported through importlib.  On a clean checkout the native
+    libraries are compiled first (hipcc cross-compiles gfx950 without a GPU); the product itself never builds or falls
+    back on its own — it raises if libmirt.so is missing."""
+    mirt = importlib.import_module("cpu-raytracing-experiments_amd")
+    if not os.path.exists(mirt.LIB_PATH):
+        mirt.build()
+    return mirt
 
 
 @pytest.fixture(scope="session")
