@@ -174,31 +174,41 @@ MIRT_DI bool sphere_occludes(float4 s, float px, float py, float pz, float dx, f
 // tested against the ray inflated by alpha*t (L-inf) at parameter t:
 //     lo_i - alpha t <= p_i + t d_i <= hi_i + alpha t   <=>   t (d_i+alpha) >= lo_i - p_i   and   t (d_i-alpha) <= hi_i - p_i
 // i.e. the usual slab test with reciprocal 1/(d_i+alpha) for the lo plane and 1/(d_i-alpha) for the hi plane (still one FMA
-// per plane).  An axis with |d_i| <= alpha yields two lower bounds and is dropped (lo -> -inf, hi -> +inf), which also
-// covers zero direction components.  For unit directions alpha = 1.4e-3: +4 % box tests on S(1000).
-struct RaySlab { float iax, iay, iaz, nax, nay, naz, ibx, iby, ibz, nbx, nby, nbz; };
-MIRT_DI void slab_axis(float p, float d, float alpha, float& ia, float& na, float& ib, float& nb) {
-	const bool keep = fabs_bits(d) > alpha;
-	const float r = 1.0f / ((d - alpha) * (d + alpha));         // one division per axis: 1/(d+a) = (d-a)/(d^2-a^2), 1/(d-a) = (d+a)/(d^2-a^2)
+// per plane).  An axis with |d_i| < alpha has d_i+alpha > 0 > d_i-alpha: BOTH planes give lower bounds on t and there is no
+// upper bound (the cone widens faster than the ray drifts).  Such axes cannot simply be dropped: every camera ray near the
+// image's centre row/column is nearly axis-parallel, and without its lateral bounds it visits every box in front of it
+// (64 438 boxes for one ray of S(100000), a 20 ms tail per launch).  Per axis a constant c = -inf (ordinary) / +inf (both
+// lower bounds) turns the two cases into the same two instructions:
+//     enter_i = med3(l, h, c)   (min(l,h) | max(l,h))        leave_i = max3(l, h, c)   (max(l,h) | +inf)
+// |d_i| == alpha exactly: the axis gives no bound (l = -inf, h = +inf).  For unit directions alpha = 1.4e-3: +4 % box tests on S(1000).
+struct RaySlab { float iax, iay, iaz, nax, nay, naz, ibx, iby, ibz, nbx, nby, nbz, cx, cy, cz; };
+MIRT_DI void slab_axis(float p, float d, float alpha, float& ia, float& na, float& ib, float& nb, float& c) {
+	const float prod = (d - alpha) * (d + alpha);               // one division per axis: 1/(d+a) = (d-a)/(d^2-a^2), 1/(d-a) = (d+a)/(d^2-a^2)
+	const bool keep = prod != 0.0f;
+	const float r = 1.0f / prod;
 	const float ra = (d - alpha) * r, rb = (d + alpha) * r;
 	ia = keep ? ra : 0.0f; ib = keep ? rb : 0.0f;
 	na = keep ? -(p * ra) : -__builtin_inff();
 	nb = keep ? -(p * rb) : __builtin_inff();
+	c = (prod < 0.0f) ? __builtin_inff() : -__builtin_inff();
 }
-MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
+MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz, float& alpha_out) {
 	const float L2 = (dx * dx + dy * dy) + dz * dz;
 	const float a2 = __builtin_fmaxf(L2 - 1.0f, 0.0f) * 1.0009765625f + 0x1p-19f;
 	const float alpha = __builtin_sqrtf(a2) * 1.0009765625f;
+	alpha_out = alpha;
 	RaySlab s;
-	slab_axis(px, dx, alpha, s.iax, s.nax, s.ibx, s.nbx);
-	slab_axis(py, dy, alpha, s.iay, s.nay, s.iby, s.nby);
-	slab_axis(pz, dz, alpha, s.iaz, s.naz, s.ibz, s.nbz);
+	slab_axis(px, dx, alpha, s.iax, s.nax, s.ibx, s.nbx, s.cx);
+	slab_axis(py, dy, alpha, s.iay, s.nay, s.iby, s.nby, s.cy);
+	slab_axis(pz, dz, alpha, s.iaz, s.naz, s.ibz, s.nbz, s.cz);
 	return s;
 }
-// fminf/fmaxf lower to v_min_f32 / v_max_f32 (v_min3/v_max3): NaNs from 0*inf slabs are dropped.
-MIRT_DI bool slab_hit(float lx, float hx, float ly, float hy, float lz, float hz, float tfar, float& tnear) {
-	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fmaxf(__builtin_fminf(lz, hz), 0.0f));
-	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fminf(__builtin_fmaxf(lz, hz), tfar));
+// v_med3_f32 / v_max3_f32 / v_min3_f32; no NaN can reach them (finite boxes, finite or zeroed reciprocals).
+MIRT_DI bool slab_hit(const RaySlab& rs, float lx, float hx, float ly, float hy, float lz, float hz, float tfar, float& tnear) {
+	const float ex = __builtin_amdgcn_fmed3f(lx, hx, rs.cx), ey = __builtin_amdgcn_fmed3f(ly, hy, rs.cy), ez = __builtin_amdgcn_fmed3f(lz, hz, rs.cz);
+	const float ox = __builtin_fmaxf(__builtin_fmaxf(lx, hx), rs.cx), oy = __builtin_fmaxf(__builtin_fmaxf(ly, hy), rs.cy), oz = __builtin_fmaxf(__builtin_fmaxf(lz, hz), rs.cz);
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 0.0f));
+	const float tmax = __builtin_fminf(__builtin_fminf(ox, oy), __builtin_fminf(oz, tfar));
 	tnear = tmin;
 	return tmin <= tmax;
 }
@@ -268,10 +278,17 @@ struct Trav {
 // Stack entries beyond the LDS-resident ones.  Kept OUTSIDE Trav: a dynamically indexed member would pin the whole struct
 // in scratch memory (every step would then reload the ray through VMEM); alone, only this rarely-touched array lives there.
 struct TravSpill { uint32_t e[kStack - kLdsStack]; };
-MIRT_DI void trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar) {
+// Rays whose cone half-width exceeds kAlphaFat per unit of ray parameter (|D|^2 - 1 > ~1e-4: a few per million, produced
+// by the reference's ill-conditioned tangent frame) are not traversed: the inflated ray would touch most of the tree and one
+// lane would walk it serially (measured: 20-57 ms per launch on a 100k-sphere scene).  They go to a "fat ray" list and
+// k_trace_fat intersects them with every sphere, a whole workgroup per ray — literally the reference's brute-force loop.
+constexpr float kAlphaFat = 0.01f;
+MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar) {     // true = fat ray
 	t.px = px; t.py = py; t.pz = pz; t.dx = dx; t.dy = dy; t.dz = dz;
-	t.rs = make_slab(px, py, pz, dx, dy, dz);
+	float alpha;
+	t.rs = make_slab(px, py, pz, dx, dy, dz, alpha);
 	t.tfar = tfar; t.prim = -1; t.cur = 0; t.sp = 0;
+	return alpha > kAlphaFat;
 }
 // One step = one 64-B record: slab-test both children against the current tfar, intersect hit leaf children at once,
 // re-check inner children against the shrunken tfar, enter the nearer, push the other (or pop).  Returns true when this
@@ -310,10 +327,10 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	if (COUNT) n_nodes += 2;
 	const RaySlab& rs = t.rs;
 	float ta, tb;
-	bool ha = slab_hit(__builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
+	bool ha = slab_hit(rs, __builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
 	                   __builtin_fmaf(ay0, rs.iay, rs.nay), __builtin_fmaf(ay1, rs.iby, rs.nby),
 	                   __builtin_fmaf(az0, rs.iaz, rs.naz), __builtin_fmaf(az1, rs.ibz, rs.nbz), t.tfar, ta);
-	bool hb = slab_hit(__builtin_fmaf(bx0, rs.iax, rs.nax), __builtin_fmaf(bx1, rs.ibx, rs.nbx),
+	bool hb = slab_hit(rs, __builtin_fmaf(bx0, rs.iax, rs.nax), __builtin_fmaf(bx1, rs.ibx, rs.nbx),
 	                   __builtin_fmaf(by0, rs.iay, rs.nay), __builtin_fmaf(by1, rs.iby, rs.nby),
 	                   __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
 
@@ -384,6 +401,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 constexpr uint32_t kChunkMax = 512;
 constexpr uint32_t kRefillIdle = 16;
 constexpr uint32_t kNone = 0xffffffffu;
+struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
 struct WaveWindow { uint32_t beg, end, chunk; bool more; };
 // Rays per reservation: large enough that the work counter sees one atomic per several hundred rays, small enough that
 // every wave of the grid gets a few chunks even on the thin late-bounce streams.
@@ -420,7 +438,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
 template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, class LoadRay, class StoreResult>
-MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
+MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
 	WaveWindow w{ 0, 0, pick_chunk(n), true };
 	Trav t;
@@ -436,7 +454,10 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n,
 				float px, py, pz, dx, dy, dz, tf;
 				load_ray(got, px, py, pz, dx, dy, dz, tf);
 				ri = got; occluded = false;
-				trav_begin(t, px, py, pz, dx, dy, dz, tf);
+				if (trav_begin(t, px, py, pz, dx, dy, dz, tf)) {
+					const uint32_t k = atomicAdd(fat.count, 1u);               // rare: a few rays per million
+					if (k < fat.capacity) { fat.rays[k] = got; ri = kNone; }   // list full -> traverse it after all (correct, only slow)
+				}
 			}
 		}
 		const bool work_left = w.more || w.beg != w.end;
@@ -525,16 +546,16 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // ------------------------------------------------------------------------------------------------
 // Drain one ray queue with the persistent-wave loop (dispatch on the staged-BVH variant).
 template <bool ANYHIT, bool COUNT, class LoadRay, class StoreResult>
-MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, uint32_t& c_nodes, uint32_t& c_spheres,
+MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                          LoadRay load_ray, StoreResult store_result) {
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
-		if (all) trace_persistent<ANYHIT, COUNT, true, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, true>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		if (all) trace_persistent<ANYHIT, COUNT, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	} else {
-		if (all) trace_persistent<ANYHIT, COUNT, true, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, false>(sc, tl, n, work_next, c_nodes, c_spheres, load_ray, store_result);
+		if (all) trace_persistent<ANYHIT, COUNT, true, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	}
 }
 
@@ -549,7 +570,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                        const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
                                                        ShadowBuf sh, uint32_t* __restrict__ occ_out,
-                                                       const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, DevCounters* ctr) {
+                                                       const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
+                                                       DevCounters* ctr) {
 	extern __shared__ float4 lds[];
 	const uint32_t nc = *closest_count, ns = *shadow_count;
 	if (nc + ns == 0) return;
@@ -566,14 +588,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 				px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
 			};
 			auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
-			trace_queue<false, COUNT>(sc, tl, nc, closest_work, c_nodes, c_spheres, load_ray, store_result);
+			trace_queue<false, COUNT>(sc, tl, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
 		{
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
 				px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 			};
 			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
-			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, s_nodes, s_spheres, load_ray, store_result);
+			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
 		}
 	} else {
 		// brute force over all prims (the reference as shipped); also the no-spheres case
@@ -599,6 +621,53 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 		}
 	}
 	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); wave_sum(s_nodes, &ctr->shadow_nodes); wave_sum(s_spheres, &ctr->shadow_spheres); }
+}
+
+// Fat rays (see trav_begin): one workgroup per ray runs the reference's brute-force loops over ALL prims —
+// intersect_prims (BVH.hpp:236-288; closest = lexicographic minimum of (dist, prim index), i.e. the ascending strict-'<' scan)
+// for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
+template <bool COUNT>
+__global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
+                                                    ShadowBuf sh, uint32_t* __restrict__ occ_out, FatList fat_shadow, DevCounters* ctr) {
+	__shared__ float s_t[16];
+	__shared__ int32_t s_p[16];
+	const uint32_t nc = min(*fat_closest.count, fat_closest.capacity), ns = min(*fat_shadow.count, fat_shadow.capacity);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+	for (uint32_t k = blockIdx.x; k < nc; k += gridDim.x) {
+		const uint32_t i = fat_closest.rays[k];
+		const float px = in.px[i], py = in.py[i], pz = in.pz[i], dx = in.dx[i], dy = in.dy[i], dz = in.dz[i];
+		float tfar = MIRT_FLT_MAX; int32_t prim = -1;
+		for (uint32_t p = threadIdx.x; p < sc.n_spheres; p += blockDim.x) sphere_closest(sc.spheres[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, prim);
+		// lexicographic (dist, prim) minimum across the workgroup; prim -1 = no hit, always loses (its tfar is FLT_MAX and every hit is < FLT_MAX)
+		for (int off = 32; off > 0; off >>= 1) {
+			const float ot = __shfl_down(tfar, off, 64); const int32_t op = __shfl_down(prim, off, 64);
+			const bool take = (op >= 0) & ((prim < 0) | (ot < tfar) | ((ot == tfar) & (op < prim)));
+			tfar = take ? ot : tfar; prim = take ? op : prim;
+		}
+		__syncthreads();
+		if (lane == 0) { s_t[wave] = tfar; s_p[wave] = prim; }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			for (uint32_t w = 1; w < n_waves; w++) {
+				const float ot = s_t[w]; const int32_t op = s_p[w];
+				const bool take = (op >= 0) && ((prim < 0) || (ot < tfar) || ((ot == tfar) && (op < prim)));
+				if (take) { tfar = ot; prim = op; }
+			}
+			tfar_out[i] = tfar; prim_out[i] = prim;
+			if (COUNT) atomicAdd(&ctr->spheres, static_cast<unsigned long long>(sc.n_spheres));
+		}
+	}
+	for (uint32_t k = blockIdx.x; k < ns; k += gridDim.x) {
+		const uint32_t i = fat_shadow.rays[k];
+		const float px = sh.px[i], py = sh.py[i], pz = sh.pz[i], dx = sh.dx[i], dy = sh.dy[i], dz = sh.dz[i], tfar = sh.tfar[i];
+		bool occ = false;
+		for (uint32_t p = threadIdx.x; p < sc.n_spheres && !occ; p += blockDim.x) occ = sphere_occludes(sc.spheres[p], px, py, pz, dx, dy, dz, tfar);
+		const int any = __syncthreads_or(occ ? 1 : 0);
+		if (threadIdx.x == 0) {
+			occ_out[i] = any ? 1u : 0u;
+			if (COUNT) atomicAdd(&ctr->shadow_spheres, static_cast<unsigned long long>(sc.n_spheres));
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -850,29 +919,6 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ ac
 // ------------------------------------------------------------------------------------------------
 // Stage-level debug kernels (mirt_debug_*)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTraceBlock) void k_debug_shadow(SceneDev sc, const float* p, const float* d, const float* tfar_in, uint8_t* occ, uint32_t n) {
-	extern __shared__ float4 lds[];
-	uint32_t c0 = 0, c1 = 0;
-	if (blockIdx.x * kTraceBlock >= n) return;
-	TraceLds tl{ nullptr, nullptr, nullptr };
-	const bool bvh = sc.use_bvh && sc.n_recs != 0;
-	if (bvh) tl = stage_bvh(sc, lds);
-	for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
-		const uint32_t i = base + threadIdx.x;
-		const bool active = i < n;
-		float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
-		if (active) { px = p[i]; py = p[n + i]; pz = p[2 * n + i]; dx = d[i]; dy = d[n + i]; dz = d[2 * n + i]; tfar = tfar_in[i]; }
-		bool o = false; int32_t dummy = -1;
-		if (bvh) {
-			if (active) {
-				Trav t; TravSpill spill; trav_begin(t, px, py, pz, dx, dy, dz, tfar);
-				if (sc.half_boxes) { while (!trav_step<true, false, false, true>(sc, tl, t, spill, o, c0, c1)) {} }
-				else { while (!trav_step<true, false, false, false>(sc, tl, t, spill, o, c0, c1)) {} }
-			}
-		} else if (sc.use_bvh == 0) o = traverse_brute<true, false>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, c1);
-		if (active) occ[i] = o ? 1 : 0;
-	}
-}
 __global__ __launch_bounds__(kBlock) void k_debug_math(int fn, uint32_t n, const float* in, float* out) {
 	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
 		switch (fn) {

@@ -49,6 +49,7 @@ struct PipeSlot {
 	DeviceBuffer arena;              // ray streams
 	DeviceBuffer counts;             // stream_count[nb+1] | shadow_count[nb] | work_next[nb] | work_next_shadow[nb] | zero word
 	DeviceBuffer contrib;            // this batch's adds, same layout as the accumulator
+	DeviceBuffer fat;                // fat-ray index lists: [closest kFatCapacity][shadow kFatCapacity]
 	hipEvent_t batch_done = nullptr; // recorded on `stream` after the batch's last kernel
 	hipEvent_t merged = nullptr;     // recorded on the main stream after the batch was merged (slot reusable)
 	bool in_use = false;
@@ -144,6 +145,7 @@ hipError_t sync_all(mirt_ctx* c) {
 	for (PipeSlot& sl : c->slots) if (sl.stream) { hipError_t e = hipStreamSynchronize(sl.stream); if (e != hipSuccess) return e; }
 	return hipStreamSynchronize(c->stream);
 }
+constexpr uint32_t kFatCapacity = 1u << 16;   // rays per list and launch that may take the brute-force detour (a few per million qualify)
 uint32_t wanted_slots(const mirt_ctx* c) { const uint32_t s = c->policy.streams ? c->policy.streams : 3u; return s > 8u ? 8u : s; }
 
 // Carve each slot's frame-wide ray streams out of one allocation.
@@ -161,7 +163,7 @@ int ensure_streams(mirt_ctx* c) {
 	HIP_TRY(c, sync_all(c));
 	while (c->slots.size() > want) {
 		PipeSlot& sl = c->slots.back();
-		sl.arena.release(); sl.counts.release(); sl.contrib.release();
+		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -179,7 +181,8 @@ int ensure_streams(mirt_ctx* c) {
 	for (PipeSlot& sl : c->slots) {
 		sl.in_use = false;
 		HIP_TRY(c, sl.arena.ensure(planes * plane_bytes));
-		HIP_TRY(c, sl.counts.ensure((static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t)));
+		HIP_TRY(c, sl.counts.ensure((static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t)));
+		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 		if (want > 1) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
 		char* p = sl.arena.as<char>();
 		auto take = [&]() { void* r = p; p += plane_bytes; return r; };
@@ -281,7 +284,9 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	uint32_t* shadow_count = stream_count + nb + 1;
 	uint32_t* work_next = shadow_count + nb;            // per-launch work counters of the persistent trace kernels
 	uint32_t* work_next_shadow = work_next + nb;
-	const uint32_t* zero_count = work_next_shadow + nb; // an always-zero count ("no shadow rays pending")
+	uint32_t* fat_n_closest = work_next_shadow + nb;    // per-launch fat-ray counts (closest-hit list, shadow list)
+	uint32_t* fat_n_shadow = fat_n_closest + nb;
+	const uint32_t* zero_count = fat_n_shadow + nb;     // an always-zero count ("no shadow rays pending")
 	DevCounters* ctr = c->counters.as<DevCounters>();
 	float* accum = pipelined ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
@@ -296,7 +301,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		if (sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));      // the slot's previous batch has been merged: buffers are free
 		HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, acc_floats * sizeof(float), st));
 	}
-	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 4 + 8) * sizeof(uint32_t), st));
+	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t), st));
 	{ Bracket t(c, MIRT_K_RAYGEN, st);
 	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, st, fp, sl.stream_buf[0], stream_count); }
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
@@ -306,10 +311,16 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		{ Bracket t(c, MIRT_K_TRACE, st);
 		  const uint32_t* sc_count = shadow_pending ? shadow_count + (bounce - 1) : zero_count;
 		  uint32_t* sc_work = work_next_shadow + (shadow_pending ? bounce - 1 : 0);
+		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
+		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, ctr);
+		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, fc, fs, ctr);
 		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, ctr); }
+		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, fc, fs, ctr);
+		  if (sc.use_bvh) {                                           // the few rays too "fat" for the tree: brute force, one workgroup each
+		    if (count) hipLaunchKernelGGL(k_trace_fat<true>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sl.shadow_occ, fs, ctr);
+		    else       hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sl.shadow_occ, fs, ctr);
+		  } }
 		if (shadow_pending) {
 			// the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
 			Bracket t(c, MIRT_K_SHADOW, st);
@@ -384,7 +395,7 @@ int mirt_destroy(mirt_ctx* c) {
 	(void)sync_all(c);
 	harvest(c);
 	for (PipeSlot& sl : c->slots) {
-		sl.arena.release(); sl.counts.release(); sl.contrib.release();
+		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -479,7 +490,6 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 		const int lds_max = static_cast<int>(kLdsPerCu);
 		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_shadow), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 	}
 	for (int k = 0; k < 3; k++) s.ambient[k] = ambient_color[k];
 	s.hdri_w = static_cast<int32_t>(hdri_w); s.hdri_h = static_cast<int32_t>(hdri_h);
@@ -670,8 +680,8 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	DeviceBuffer rays, res, cnt;
-	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(16));
-	HIP_TRY(c, hipMemset(cnt.ptr, 0, 16));
+	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(32));
+	HIP_TRY(c, hipMemset(cnt.ptr, 0, 32));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
@@ -683,14 +693,17 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	DevCounters* scratch_ctr = nullptr;
 	DeviceBuffer ctr; HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
-	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter }
+	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter, fat count closest, fat count shadow }
+	DeviceBuffer fat; HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
+	const FatList fc{ cnt.as<uint32_t>() + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cnt.as<uint32_t>() + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
-	                   ShadowBuf{}, static_cast<uint32_t*>(nullptr), cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, scratch_ctr);
+	                   ShadowBuf{}, static_cast<uint32_t*>(nullptr), cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, fc, fs, scratch_ctr);
+	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, static_cast<uint32_t*>(nullptr), fs, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
 	if (e == hipSuccess) e = hipMemcpy(prim_out, res.as<float>() + n, n * 4, hipMemcpyDeviceToHost);
-	rays.release(); res.release(); cnt.release(); ctr.release();
+	rays.release(); res.release(); cnt.release(); ctr.release(); fat.release();
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_closest: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }
@@ -700,18 +713,31 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
 	if (!p_xyz || !dir_xyz || !tfar || !occluded_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
-	DeviceBuffer rays, occ;
-	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n));
+	DeviceBuffer rays, occ, cnt, ctr, fat;
+	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n * 4)); HIP_TRY(c, cnt.ensure(32)); HIP_TRY(c, ctr.ensure(sizeof(DevCounters)));
+	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 6 * n, tfar, n * 4, hipMemcpyHostToDevice));
+	// cnt = { 0 (no closest-hit rays), work counter, n, shadow work counter, fat count closest, fat count shadow }
+	const uint32_t host_cnt[8] = { 0, 0, static_cast<uint32_t>(n), 0, 0, 0, 0, 0 };
+	HIP_TRY(c, hipMemcpy(cnt.ptr, host_cnt, 32, hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemset(ctr.ptr, 0, sizeof(DevCounters)));
 	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
-	hipLaunchKernelGGL(k_debug_shadow, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, d, d + 3 * n, d + 6 * n, occ.as<uint8_t>(), static_cast<uint32_t>(n));
+	ShadowBuf sh{}; sh.px = d; sh.py = d + n; sh.pz = d + 2 * n; sh.dx = d + 3 * n; sh.dy = d + 4 * n; sh.dz = d + 5 * n; sh.tfar = d + 6 * n;
+	uint32_t* cn = cnt.as<uint32_t>();
+	const FatList fc{ cn + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cn + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
+	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass
+	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), cn, cn + 1,
+	                   sh, occ.as<uint32_t>(), cn + 2, cn + 3, fc, fs, ctr.as<DevCounters>());
+	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, occ.as<uint32_t>(), fs, ctr.as<DevCounters>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	if (e == hipSuccess) e = hipMemcpy(occluded_out, occ.ptr, n, hipMemcpyDeviceToHost);
-	rays.release(); occ.release();
+	std::vector<uint32_t> host_occ(n);
+	if (e == hipSuccess) e = hipMemcpy(host_occ.data(), occ.ptr, n * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) for (size_t i = 0; i < n; i++) occluded_out[i] = host_occ[i] ? 1 : 0;
+	rays.release(); occ.release(); cnt.release(); ctr.release(); fat.release();
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_shadow: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }

@@ -692,29 +692,39 @@ static void bvh_quantize_half(BVH& bvh) {
 // which is the usual slab test with reciprocal 1/(d_i+alpha) for the lo plane and 1/(d_i-alpha) for the hi plane; an
 // axis with |d_i| <= alpha gives two lower bounds and is dropped (lo -> -inf, hi -> +inf).
 static float g_cone_fuzz = 0x1p-19f;
-struct RaySlab { float ia[3], na[3], ib[3], nb[3]; };
-static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz) {
+struct RaySlab { float ia[3], na[3], ib[3], nb[3], c[3]; };
+// Rays with alpha > kAlphaFat skip the tree: the product hands them to k_trace_fat, which runs the brute-force loops
+// over all prims (csrc/kernels.hpp trav_begin / k_trace_fat); counters then grow by the prim count, no boxes.
+static constexpr float kAlphaFat = 0.01f;
+static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz, bool* fat) {
 	RaySlab s;
 	const float L2 = (dx * dx + dy * dy) + dz * dz;
 	const float a2 = fmaxf(L2 - 1.0f, 0.0f) * 1.0009765625f + g_cone_fuzz;
 	const float alpha = sqrtf(a2) * 1.0009765625f;
+	*fat = alpha > kAlphaFat;
 	const float p[3] = { px, py, pz }, d[3] = { dx, dy, dz };
 	for (int a = 0; a < 3; a++) {
-		if (!(fast_abs(d[a]) > alpha)) { s.ia[a] = 0.0f; s.ib[a] = 0.0f; s.na[a] = -INFINITY; s.nb[a] = INFINITY; }
+		const float prod = (d[a] - alpha) * (d[a] + alpha);                // as slab_axis() in csrc/kernels.hpp
+		if (prod == 0.0f) { s.ia[a] = 0.0f; s.ib[a] = 0.0f; s.na[a] = -INFINITY; s.nb[a] = INFINITY; }
 		else {
-			const float r = 1.0f / ((d[a] - alpha) * (d[a] + alpha));      // as slab_axis() in csrc/kernels.hpp
+			const float r = 1.0f / prod;
 			s.ia[a] = (d[a] - alpha) * r; s.ib[a] = (d[a] + alpha) * r; s.na[a] = -(p[a] * s.ia[a]); s.nb[a] = -(p[a] * s.ib[a]);
 		}
+		s.c[a] = (prod < 0.0f) ? INFINITY : -INFINITY;                      // |d| < alpha: both planes bound t from below, no upper bound
 	}
 	return s;
 }
-// slab test on [0, tfar]; fminf/fmaxf drop NaNs exactly like v_min_f32 / v_max_f32
+// slab test on [0, tfar]; per axis enter = med3(l, h, c), leave = max3(l, h, c) with c = -inf (ordinary axis) or +inf
+// (|d| < alpha), see kernels.hpp slab_hit(); no NaN reaches the selections
+static inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline bool slab_test(const RaySlab& s, const Box& b, float tfar, float* tnear) {
 	const float lx = fmaf(b.mn[0], s.ia[0], s.na[0]), hx = fmaf(b.mx[0], s.ib[0], s.nb[0]);
 	const float ly = fmaf(b.mn[1], s.ia[1], s.na[1]), hy = fmaf(b.mx[1], s.ib[1], s.nb[1]);
 	const float lz = fmaf(b.mn[2], s.ia[2], s.na[2]), hz = fmaf(b.mx[2], s.ib[2], s.nb[2]);
-	const float tmin = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), 0.0f));
-	const float tmax = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tfar));
+	const float ex = med3(lx, hx, s.c[0]), ey = med3(ly, hy, s.c[1]), ez = med3(lz, hz, s.c[2]);
+	const float ox = fmaxf(fmaxf(lx, hx), s.c[0]), oy = fmaxf(fmaxf(ly, hy), s.c[1]), oz = fmaxf(fmaxf(lz, hz), s.c[2]);
+	const float tmin = fmaxf(fmaxf(ex, ey), fmaxf(ez, 0.0f));
+	const float tmax = fminf(fminf(ox, oy), fminf(oz, tfar));
 	*tnear = tmin;
 	return tmin <= tmax;
 }
@@ -731,7 +741,13 @@ static inline void sphere_closest_tie(const Sphere& s, int32_t prim_ID, float px
 // shrunken tfar, the nearer one is entered first and the other pushed.  (The root box itself is not tested.)
 static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz,
                                 float* tfar, int32_t* primID, LocalCounters& lc) {
-	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
+	bool fat;
+	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz, &fat);
+	if (fat) {
+		for (size_t p = 0; p < prims.size(); p++) sphere_closest_tie(prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, primID);
+		lc.spheres += prims.size();
+		return;
+	}
 	auto leaf = [&](const Node& n) {
 		for (uint32_t slot = n.first_id; slot < n.first_id + n.prim_count; slot++) {
 			const uint32_t p = bvh.slot_prim.empty() ? slot : bvh.slot_prim[slot];
@@ -772,7 +788,14 @@ static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims
 }
 static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz,
                                        float tfar, LocalCounters& lc) {
-	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz);
+	bool fat;
+	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz, &fat);
+	if (fat) {
+		bool occ = false;
+		for (size_t p = 0; p < prims.size(); p++) occ |= sphere_occludes(prims[p], px, py, pz, dx, dy, dz, tfar);
+		lc.shadow_spheres += prims.size();
+		return occ;
+	}
 	auto leaf = [&](const Node& n) {
 		for (uint32_t slot = n.first_id; slot < n.first_id + n.prim_count; slot++) {
 			lc.shadow_spheres++;
@@ -1266,6 +1289,7 @@ void orc_trace_closest(void* h, int trav_mode, size_t n, const float* p_xyz, con
 		else if (!o.accel.nodes.empty()) traverse_ray(o.accel, o.bvh.prims, px, py, pz, dx, dy, dz, &t, &id, lc);
 		tfar[i] = t; primID[i] = id;
 	}
+	o.counters.rays += n; o.counters.nodes += lc.nodes; o.counters.spheres += lc.spheres;
 }
 void orc_trace_shadow(void* h, int trav_mode, size_t n, const float* p_xyz, const float* dir_xyz, const float* tfar, uint8_t* occluded) {
 	Oracle& o = *static_cast<Oracle*>(h);
@@ -1278,6 +1302,7 @@ void orc_trace_shadow(void* h, int trav_mode, size_t n, const float* p_xyz, cons
 		else if (!o.accel.nodes.empty()) occ = traverse_ray_shadow(o.accel, o.bvh.prims, px, py, pz, dx, dy, dz, tfar[i], lc);
 		occluded[i] = occ ? 1 : 0;
 	}
+	o.counters.shadow_rays += n; o.counters.shadow_nodes += lc.shadow_nodes; o.counters.shadow_spheres += lc.shadow_spheres;
 }
 
 // Path of one pixel (tile LaunchIndex, pixel px) in Accumulate() number `accumulations`: out[b*8..] = p, dir, tfar, primID per bounce.
