@@ -9,7 +9,11 @@ def load(f):
         if "mirt" not in k: continue
         d = rows[(int(row["Dispatch_Id"]), k)]
         d[row["Counter_Name"]] = float(row["Counter_Value"]); d["us"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
-    return rows
+    # dispatch ids of the two passes need not agree (other libraries launch kernels too): key by (n-th launch of this kernel, name)
+    out, seen = {}, collections.Counter()
+    for (_, k), d in sorted(rows.items()):
+        out[(seen[k], k)] = d; seen[k] += 1
+    return out
 r1 = load(glob.glob(f"{root}/p1/*/*_counter_collection.csv")[0]); r2 = load(glob.glob(f"{root}/p2/*/*_counter_collection.csv")[0])
 pat = sys.argv[2] if len(sys.argv) > 2 else "trace"
 for (i, k), d in sorted(r1.items()):
