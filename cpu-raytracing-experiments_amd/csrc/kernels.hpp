@@ -4,12 +4,12 @@
 // 16x16 tile through raygen -> [intersect -> closest-hit shade -> sort -> NEE -> shadow trace ->
 // emissive -> BRDF sample/RR/compaction -> miss -> accumulate] on one CPU thread.  Here the same
 // path state is a set of SoA ray streams in HBM spanning every pixel this GPU owns times the
-// accumulations in flight, and one bounce is three kernels:
+// accumulations in flight, and one bounce is two kernels (plus a few-microsecond k_trace_fat for the rare stretched rays):
 //
 //   k_trace           Traverse (BVH.hpp:309-360) for the rays of bounce b: reads p,dir, writes tfar,primID — and, in the
-//                     same launch, Traverse_shadow (BVH.hpp:362-404) for the NEE rays of bounce b-1: one occlusion flag each
-//   k_shadow_resolve  Renderer.hpp:304-314 and the deferred radiance finalisation ((R + unoccluded NEE) + emissive),
-//                     in the reference's add order, for the shadow rays just traced
+//                     same launch, Traverse_shadow (BVH.hpp:362-404) for the NEE rays of bounce b-1, each followed by
+//                     Renderer.hpp:304-314 and the deferred radiance finalisation ((R + unoccluded NEE) + emissive) in the
+//                     reference's add order
 //   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into the next stream and
 //                     NEE candidates into the shadow stream (wave64 ballot + mbcnt prefix sums, one atomic per workgroup)
 //
@@ -559,6 +559,44 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Accumulator addressing + the deferred shadow-ray adds
+// ------------------------------------------------------------------------------------------------
+MIRT_DI size_t accum_index(uint32_t acc_base, uint32_t buckets, uint32_t path) {
+	const uint32_t slot = (path >> 24) & 0x7fu;
+	const uint32_t pix = path & 0xffffffu;
+	const uint32_t bucket = (acc_base + slot + 1u) % buckets;               // Renderer.hpp:82
+	return (static_cast<size_t>(pix >> 8) * buckets + bucket) * 3u * kTileSize + (pix & 255u);
+}
+MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) { return accum_index(fp.acc_base, fp.buckets, path); }
+MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, float g, float b) {     // Renderer.hpp:427-429
+	// (pixel, bucket) is unique within a batch and batches are stream-ordered: plain read-modify-write, no atomics,
+	// and each bucket sees its adds in accumulation order exactly like the reference.
+	accum[idx] += r; accum[idx + kTileSize] += g; accum[idx + 2 * kTileSize] += b;
+}
+// Where a finished shadow ray's radiance goes.  The adds that had to wait for the occlusion test — (R + unoccluded NEE) +
+// emissive, the reference's order (Renderer.hpp:307-311, then 339-341 / 348-350) — are made by the lane that traced the
+// ray, straight into the next stream's radiance planes or the accumulator: k_trace is VALU-bound, so the ~16 memory
+// instructions per shadow ray ride along for free, where a separate pass over the shadow stream cost 4.8 ms per cfg2 step.
+// occ != nullptr (mirt_debug_trace_shadow): only the occlusion flag is stored.
+struct ShadowSink {
+	float *rr, *rg, *rb;        // radiance planes of the stream k_shade reads next
+	float* accum;
+	uint32_t acc_base, buckets;
+	uint32_t* occ;
+};
+MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t i, bool occluded, uint32_t& c_term) {
+	if (sink.occ) { sink.occ[i] = occluded ? 1u : 0u; return; }
+	f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
+	const f3 S{ sh.sr[i], sh.sg[i], sh.sb[i] };
+	const f3 E{ sh.er[i], sh.eg[i], sh.eb[i] };
+	const uint32_t dest = sh.dest[i];
+	R.x = occluded ? R.x : R.x + S.x; R.y = occluded ? R.y : R.y + S.y; R.z = occluded ? R.z : R.z + S.z;
+	R.x += E.x; R.y += E.y; R.z += E.z;
+	if (dest & kDestAccum) { c_term++; accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), R.x, R.y, R.z); }
+	else { sink.rr[dest] = R.x; sink.rg[dest] = R.y; sink.rb[dest] = R.z; }
+}
+
 // INTERSECTION + SHADOW RAY TRACING in one launch: Traverse (BVH.hpp:309-360) for the rays of bounce b and
 // Traverse_shadow (BVH.hpp:362-404) for the NEE rays emitted at bounce b-1 — the two queues are independent, and every
 // launch ends with a tail while its longest rays finish (~180 us at 16k+ rays, measured), so draining both in one
@@ -569,7 +607,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                        const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
-                                                       ShadowBuf sh, uint32_t* __restrict__ occ_out,
+                                                       ShadowBuf sh, ShadowSink sink,
                                                        const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
                                                        DevCounters* ctr) {
 	extern __shared__ float4 lds[];
@@ -579,7 +617,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 		if (nc) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));
 		if (ns) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(ns));
 	}
-	uint32_t c_nodes = 0, c_spheres = 0, s_nodes = 0, s_spheres = 0;
+	uint32_t c_nodes = 0, c_spheres = 0, s_nodes = 0, s_spheres = 0, c_term = 0;
 	if (sc.use_bvh && sc.n_recs != 0) {
 		if (static_cast<uint64_t>(blockIdx.x) * 64u >= static_cast<uint64_t>(nc) + ns) return;   // more workgroups than minimum-size chunks: skip the staging too
 		const TraceLds tl = stage_bvh(sc, lds);
@@ -594,7 +632,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
 				px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 			};
-			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { occ_out[i] = occluded ? 1u : 0u; };
+			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { shadow_finish(sh, sink, i, occluded, c_term); };
 			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
 		}
 	} else {
@@ -617,9 +655,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 			bool occluded = false;
 			int32_t dummy = -1;
 			if (sc.use_bvh == 0) occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, s_spheres);
-			if (active) occ_out[i] = occluded ? 1u : 0u;
+			if (active) shadow_finish(sh, sink, i, occluded, c_term);
 		}
 	}
+	wave_sum(c_term, &ctr->terminated);
 	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); wave_sum(s_nodes, &ctr->shadow_nodes); wave_sum(s_spheres, &ctr->shadow_spheres); }
 }
 
@@ -628,7 +667,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
 // for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
-                                                    ShadowBuf sh, uint32_t* __restrict__ occ_out, FatList fat_shadow, DevCounters* ctr) {
+                                                    ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr) {
 	__shared__ float s_t[16];
 	__shared__ int32_t s_p[16];
 	const uint32_t nc = min(*fat_closest.count, fat_closest.capacity), ns = min(*fat_shadow.count, fat_shadow.capacity);
@@ -664,7 +703,9 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, f
 		for (uint32_t p = threadIdx.x; p < sc.n_spheres && !occ; p += blockDim.x) occ = sphere_occludes(sc.spheres[p], px, py, pz, dx, dy, dz, tfar);
 		const int any = __syncthreads_or(occ ? 1 : 0);
 		if (threadIdx.x == 0) {
-			occ_out[i] = any ? 1u : 0u;
+			uint32_t c_term = 0;
+			shadow_finish(sh, sink, i, any != 0, c_term);
+			if (c_term) atomicAdd(&ctr->terminated, 1ull);
 			if (COUNT) atomicAdd(&ctr->shadow_spheres, static_cast<unsigned long long>(sc.n_spheres));
 		}
 	}
@@ -673,18 +714,6 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, f
 // ------------------------------------------------------------------------------------------------
 // Accumulator addressing — AccumulationTile<k>, Renderer.hpp:43-46,84: [tile][bucket][r,g,b][256]
 // ------------------------------------------------------------------------------------------------
-MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) {
-	const uint32_t slot = (path >> 24) & 0x7fu;
-	const uint32_t pix = path & 0xffffffu;
-	const uint32_t bucket = (fp.acc_base + slot + 1u) % fp.buckets;         // Renderer.hpp:82
-	return (static_cast<size_t>(pix >> 8) * fp.buckets + bucket) * 3u * kTileSize + (pix & 255u);
-}
-MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, float g, float b) {     // Renderer.hpp:427-429
-	// (pixel, bucket) is unique within a batch and batches are stream-ordered: plain read-modify-write, no atomics,
-	// and each bucket sees its adds in accumulation order exactly like the reference.
-	accum[idx] += r; accum[idx + kTileSize] += g; accum[idx + 2 * kTileSize] += b;
-}
-
 // Sky::operator(), Primitives.hpp:35-46
 MIRT_DI f3 sky_eval(const SceneDev& sc, float x, float y, float z) {
 	const float ex = sc.hdri_fw * (0.5f + MIRT_INV_TWO_PI * fast_atan2(z, x));
@@ -835,7 +864,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			out.path[slot] = path;
 		}
 		if (has_shadow) {
-			// radiance is finalised by k_shadow_resolve once k_trace has the occlusion flag: (R + unoccluded NEE) + E
+			// radiance is finalised by k_trace (shadow_finish) once it knows the occlusion: (R + unoccluded NEE) + E
 			sh.px[sslot] = P.x; sh.py[sslot] = P.y; sh.pz[sslot] = P.z;
 			sh.dx[sslot] = L.x; sh.dy[sslot] = L.y; sh.dz[sslot] = L.z;
 			sh.tfar[sslot] = light_distance;
@@ -853,26 +882,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	}
 	wave_sum(c_term, &ctr->terminated);
 	wave_sum(c_drop, &ctr->dropped);
-}
-
-// ------------------------------------------------------------------------------------------------
-// SHADOW RAY TRACING + accumulation — Traverse_shadow (BVH.hpp:362-404), Renderer.hpp:304-314
-// ------------------------------------------------------------------------------------------------
-// Shadow accumulation + deferred radiance finalisation: (R + unoccluded NEE) + emissive, the reference's add order
-// (Renderer.hpp:307-311, then 339-341 / 348-350), written to the next stream's radiance slot or added to the accumulator.
-__global__ __launch_bounds__(kBlock) void k_shadow_resolve(FrameParams fp, ShadowBuf sh, const uint32_t* __restrict__ occ, StreamBuf out, uint32_t bounce,
-                                                           const uint32_t* __restrict__ shadow_count, float* __restrict__ accum, DevCounters* ctr) {
-	const uint32_t n = shadow_count[bounce];
-	uint32_t c_term = 0;
-	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-		f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
-		if (occ[i] == 0u) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }
-		R.x += sh.er[i]; R.y += sh.eg[i]; R.z += sh.eb[i];
-		const uint32_t dest = sh.dest[i];
-		if (dest & kDestAccum) { c_term++; accumulate_add(accum, accum_index(fp, dest & ~kDestAccum), R.x, R.y, R.z); }
-		else { out.rr[dest] = R.x; out.rg[dest] = R.y; out.rb[dest] = R.z; }
-	}
-	wave_sum(c_term, &ctr->terminated);
 }
 
 // In-order merge of one batch's contribution buffer into the accumulator (see launch_batch in mirt_capi.hip): exactly the

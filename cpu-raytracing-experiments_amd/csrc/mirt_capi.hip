@@ -41,6 +41,14 @@ struct DeviceBuffer {
 	template <class T> T* as() const { return static_cast<T*>(ptr); }
 };
 
+// Function-local buffers of the debug entry points: freed on every return path.
+struct ScopedBuffer : DeviceBuffer {
+	ScopedBuffer() = default;
+	ScopedBuffer(const ScopedBuffer&) = delete;
+	ScopedBuffer& operator=(const ScopedBuffer&) = delete;
+	~ScopedBuffer() { release(); }
+};
+
 struct TimedLaunch { int klass; hipEvent_t start, stop; };
 
 // One batch in flight: its own HIP stream, ray streams and (when more than one slot exists) contribution buffer.
@@ -57,7 +65,6 @@ struct PipeSlot {
 	ShadowBuf shadow_buf{};
 	float* hit_tfar = nullptr;
 	int32_t* hit_prim = nullptr;
-	uint32_t* shadow_occ = nullptr;  // one occlusion flag per shadow ray (k_trace -> k_shadow_resolve)
 };
 
 } // namespace
@@ -176,7 +183,7 @@ int ensure_streams(mirt_ctx* c) {
 		HIP_TRY(c, hipEventCreateWithFlags(&sl.merged, hipEventDisableTiming));
 		c->slots.push_back(sl);
 	}
-	const size_t planes = 2 * 14 + 2 + 17 + 1;
+	const size_t planes = 2 * 14 + 2 + 17;           // two ray streams, hit (tfar, prim), shadow stream
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	for (PipeSlot& sl : c->slots) {
 		sl.in_use = false;
@@ -202,7 +209,6 @@ int ensure_streams(mirt_ctx* c) {
 		h.rr = (float*)take(); h.rg = (float*)take(); h.rb = (float*)take();
 		h.er = (float*)take(); h.eg = (float*)take(); h.eb = (float*)take();
 		h.dest = (uint32_t*)take();
-		sl.shadow_occ = (uint32_t*)take();
 	}
 	c->capacity = cap;
 	c->arena_bounces = nb;
@@ -313,19 +319,16 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  uint32_t* sc_work = work_next_shadow + (shadow_pending ? bounce - 1 : 0);
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
+		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
+		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.acc_base, fp.buckets, nullptr };
 		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, fc, fs, ctr);
+		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
 		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sl.shadow_occ, sc_count, sc_work, fc, fs, ctr);
+		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
 		  if (sc.use_bvh) {                                           // the few rays too "fat" for the tree: brute force, one workgroup each
-		    if (count) hipLaunchKernelGGL(k_trace_fat<true>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sl.shadow_occ, fs, ctr);
-		    else       hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sl.shadow_occ, fs, ctr);
+		    if (count) hipLaunchKernelGGL(k_trace_fat<true>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
+		    else       hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
 		  } }
-		if (shadow_pending) {
-			// the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-			Bracket t(c, MIRT_K_SHADOW, st);
-			hipLaunchKernelGGL(k_shadow_resolve, dim3(grid), dim3(kBlock), 0, st, fp, sl.shadow_buf, sl.shadow_occ, in, bounce - 1, shadow_count, accum, ctr);
-		}
 		{ Bracket t(c, MIRT_K_SHADE, st);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
@@ -679,7 +682,7 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
 	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
-	DeviceBuffer rays, res, cnt;
+	ScopedBuffer rays, res, cnt, ctr, fat;
 	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(32));
 	HIP_TRY(c, hipMemset(cnt.ptr, 0, 32));
 	float* d = rays.as<float>();
@@ -691,19 +694,18 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	in.px = d; in.py = d + n; in.pz = d + 2 * n; in.dx = d + 3 * n; in.dy = d + 4 * n; in.dz = d + 5 * n;
 	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
 	DevCounters* scratch_ctr = nullptr;
-	DeviceBuffer ctr; HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
+	HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
 	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter, fat count closest, fat count shadow }
-	DeviceBuffer fat; HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
+	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	const FatList fc{ cnt.as<uint32_t>() + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cnt.as<uint32_t>() + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
-	                   ShadowBuf{}, static_cast<uint32_t*>(nullptr), cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, static_cast<uint32_t*>(nullptr), fs, scratch_ctr);
+	                   ShadowBuf{}, ShadowSink{}, cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, fc, fs, scratch_ctr);
+	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
 	if (e == hipSuccess) e = hipMemcpy(prim_out, res.as<float>() + n, n * 4, hipMemcpyDeviceToHost);
-	rays.release(); res.release(); cnt.release(); ctr.release(); fat.release();
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_closest: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }
@@ -713,7 +715,7 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
 	if (!p_xyz || !dir_xyz || !tfar || !occluded_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
-	DeviceBuffer rays, occ, cnt, ctr, fat;
+	ScopedBuffer rays, occ, cnt, ctr, fat;
 	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n * 4)); HIP_TRY(c, cnt.ensure(32)); HIP_TRY(c, ctr.ensure(sizeof(DevCounters)));
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	float* d = rays.as<float>();
@@ -728,16 +730,16 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	ShadowBuf sh{}; sh.px = d; sh.py = d + n; sh.pz = d + 2 * n; sh.dx = d + 3 * n; sh.dy = d + 4 * n; sh.dz = d + 5 * n; sh.tfar = d + 6 * n;
 	uint32_t* cn = cnt.as<uint32_t>();
 	const FatList fc{ cn + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cn + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
-	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass
+	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
+	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
 	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), cn, cn + 1,
-	                   sh, occ.as<uint32_t>(), cn + 2, cn + 3, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, occ.as<uint32_t>(), fs, ctr.as<DevCounters>());
+	                   sh, sink, cn + 2, cn + 3, fc, fs, ctr.as<DevCounters>());
+	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
 	if (e == hipSuccess) e = hipMemcpy(host_occ.data(), occ.ptr, n * 4, hipMemcpyDeviceToHost);
 	if (e == hipSuccess) for (size_t i = 0; i < n; i++) occluded_out[i] = host_occ[i] ? 1 : 0;
-	rays.release(); occ.release(); cnt.release(); ctr.release(); fat.release();
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_shadow: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }
@@ -747,14 +749,13 @@ int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) 
 	static const int n_in[8] = { 1, 2, 1, 2, 2, 6, 8, 3 }, n_out[8] = { 2, 1, 1, 3, 3, 10, 5, 5 };
 	if (fn < 0 || fn > 7 || !in || !out || n == 0 || n >= (1u << 28)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
-	DeviceBuffer din, dout;
+	ScopedBuffer din, dout;
 	HIP_TRY(c, din.ensure(n * n_in[fn] * 4)); HIP_TRY(c, dout.ensure(n * n_out[fn] * 4));
 	HIP_TRY(c, hipMemcpy(din.ptr, in, n * n_in[fn] * 4, hipMemcpyHostToDevice));
 	hipLaunchKernelGGL(k_debug_math, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, fn, static_cast<uint32_t>(n), din.as<float>(), dout.as<float>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(out, dout.ptr, n * n_out[fn] * 4, hipMemcpyDeviceToHost);
-	din.release(); dout.release();
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_math: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }

@@ -95,7 +95,8 @@ typedef struct mirt_counters {
 	uint64_t dropped;         /* paths still alive after the last bounce, radiance dropped (Q5) */
 } mirt_counters;
 
-/* Kernel classes for mirt_get_kernel_times */
+/* Kernel classes for mirt_get_kernel_times.  MIRT_K_TRACE includes the shadow rays and their deferred adds (traced in the
+ * same launches); MIRT_K_SHADOW is kept for ABI stability and stays 0. */
 enum { MIRT_K_RAYGEN = 0, MIRT_K_TRACE = 1, MIRT_K_SHADE = 2, MIRT_K_SHADOW = 3, MIRT_K_RESOLVE = 4, MIRT_K_COUNT = 5 };
 typedef struct mirt_kernel_times {
 	double   ms[MIRT_K_COUNT];        /* summed HIP-event time per kernel class since the last reset of the timers */
