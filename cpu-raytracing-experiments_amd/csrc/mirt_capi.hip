@@ -82,7 +82,7 @@ struct mirt_ctx {
 	bool have_scene = false, have_camera = false;
 
 	// scene
-	DeviceBuffer recs, spheres, prim_mat, geom, geom_mat, mat_albedo, mat_emission, lights, hdri;
+	DeviceBuffer recs, spheres, prim_mat, light_sphere, light_emit, mat_albedo, mat_emission, hdri;
 	SceneDev scene{};
 	CameraParams camera{};
 	uint32_t trace_lds_bytes = 0;    // dynamic LDS of the BVH trace kernels (staged records + spheres)
@@ -405,7 +405,7 @@ int mirt_destroy(mirt_ctx* c) {
 	}
 	c->slots.clear();
 	for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->geom, &c->geom_mat, &c->mat_albedo, &c->mat_emission, &c->lights,
+	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->light_sphere, &c->light_emit, &c->mat_albedo, &c->mat_emission,
 	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->counters };
 	for (DeviceBuffer* b : bufs) b->release();
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -440,12 +440,20 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	if (n_spheres && n_nodes == 0) return fail(c, MIRT_ERR_ARG, "spheres without BVH nodes");
 	HIP_TRY(c, hipSetDevice(c->device));
 
-	std::vector<float4> sph(n_spheres), geo(n_spheres), alb(n_materials), emi(n_materials), sky(static_cast<size_t>(hdri_w) * hdri_h);
-	std::vector<int32_t> pm(n_spheres), gm(n_spheres), li(lights, lights + n_lights);
+	std::vector<float4> sph(n_spheres), lsp(n_lights), lem(n_lights), alb(n_materials), emi(n_materials), sky(static_cast<size_t>(hdri_w) * hdri_h);
+	std::vector<int32_t> pm(n_spheres);
 	for (uint32_t i = 0; i < n_spheres; i++) {
 		sph[i] = make_float4(bvh_prims[i].position[0], bvh_prims[i].position[1], bvh_prims[i].position[2], bvh_prims[i].radius_sq);
-		geo[i] = make_float4(geometry[i].position[0], geometry[i].position[1], geometry[i].position[2], geometry[i].radius_sq);
-		pm[i] = bvh_prims[i].material_ID; gm[i] = geometry[i].material_ID;
+		pm[i] = bvh_prims[i].material_ID;
+	}
+	// NEE reads scene.geometry[light], then material[geometry[light].material_ID].emission (Renderer.hpp:261-263,283):
+	// flattened to one table per light so the kernel makes two independent loads instead of four dependent ones
+	for (uint32_t l = 0; l < n_lights; l++) {
+		const mirt_sphere& g = geometry[lights[l]];
+		const float* e = materials[g.material_ID].emission;
+		lsp[l] = make_float4(g.position[0], g.position[1], g.position[2], g.radius_sq);
+		float id_bits; const int32_t id = lights[l]; std::memcpy(&id_bits, &id, 4);
+		lem[l] = make_float4(e[0], e[1], e[2], id_bits);
 	}
 	for (uint32_t i = 0; i < n_materials; i++) {
 		alb[i] = make_float4(materials[i].albedo[0], materials[i].albedo[1], materials[i].albedo[2], 0.0f);
@@ -471,15 +479,15 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 
 	int r;
 	if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs)) || (r = upload(c, c->spheres, sph)) || (r = upload(c, c->prim_mat, pm)) ||
-	    (r = upload(c, c->geom, geo)) || (r = upload(c, c->geom_mat, gm)) || (r = upload(c, c->mat_albedo, alb)) ||
-	    (r = upload(c, c->mat_emission, emi)) || (r = upload(c, c->lights, li)) || (r = upload(c, c->hdri, sky))) return r;
+	    (r = upload(c, c->light_sphere, lsp)) || (r = upload(c, c->light_emit, lem)) || (r = upload(c, c->mat_albedo, alb)) ||
+	    (r = upload(c, c->mat_emission, emi)) || (r = upload(c, c->hdri, sky))) return r;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 
 	SceneDev& s = c->scene;
 	s.recs = c->recs.as<float4>(); s.spheres = c->spheres.as<float4>(); s.prim_mat = c->prim_mat.as<int32_t>();
-	s.geom = c->geom.as<float4>(); s.geom_mat = c->geom_mat.as<int32_t>();
+	s.light_sphere = c->light_sphere.as<float4>(); s.light_emit = c->light_emit.as<float4>();
 	s.mat_albedo = c->mat_albedo.as<float4>(); s.mat_emission = c->mat_emission.as<float4>();
-	s.lights = c->lights.as<int32_t>(); s.hdri = c->hdri.as<float4>();
+	s.hdri = c->hdri.as<float4>();
 	s.n_spheres = n_spheres; s.n_recs = n_recs; s.n_mat = n_materials; s.n_lights = n_lights;
 	c->bvh_depth = depth;
 	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
