@@ -296,7 +296,7 @@ template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF>
 MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres) {
 	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
 	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
-	const uint32_t lstride = blockDim.x;
+	constexpr uint32_t lstride = kTraceBlock;     // every trace launch uses kTraceBlock threads (a runtime blockDim.x costs a quarter-rate v_mul_lo_u32 per push and per pop)
 	const uint32_t cur = t.cur;
 	// child boxes: (lo, hi) per axis for child 0 (a) and child 1 (b)
 	float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
