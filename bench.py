@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=None, help="accumulations per step (default: cfg2's 64)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
+    ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 32 M primary rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the counting replay (roofline.achieved becomes null)")
     args = ap.parse_args()
@@ -117,7 +118,7 @@ def main():
     first, count = mirt.distributed.tile_range(tiles, rank, world)
 
     r = mirt.Renderer(scene_fn(), device=local_rank, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True,
-                      use_bvh=bool(cfg["use_bvh"]), profile=True, streams=args.streams)
+                      use_bvh=bool(cfg["use_bvh"]), profile=True, streams=args.streams, max_batch=args.max_batch)
     n_streams = args.streams or 3
     r.Resize(width, height)
     if world > 1:

@@ -75,7 +75,9 @@ struct FrameParams {
 	uint32_t first_tile;        // first global LaunchIndex owned by this context
 	uint32_t n_pix;             // local pixels = local tiles * 256
 	uint32_t acc_base;          // `accumulations` before this batch
-	uint32_t batch_n;           // accumulations in flight (each lands in its own bucket)
+	uint32_t batch_n;           // accumulations in flight in this batch
+	uint32_t idx_base;          // where the paths' radiance is added (accum_index): straight into the accumulator (idx_base = acc_base,
+	uint32_t idx_buckets;       // idx_buckets = buckets) or into this batch's contribution buffer [tile][slot][rgb][256] (0xffffffff, batch_n)
 	uint32_t max_bounces;
 	uint32_t buckets;
 	uint32_t mis;               // MIS && light_count > 0 (Q12 guard)
@@ -567,7 +569,7 @@ MIRT_DI size_t accum_index(uint32_t acc_base, uint32_t buckets, uint32_t path) {
 	const uint32_t bucket = (acc_base + slot + 1u) % buckets;               // Renderer.hpp:82
 	return (static_cast<size_t>(pix >> 8) * buckets + bucket) * 3u * kTileSize + (pix & 255u);
 }
-MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) { return accum_index(fp.acc_base, fp.buckets, path); }
+MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) { return accum_index(fp.idx_base, fp.idx_buckets, path); }
 MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, float g, float b) {     // Renderer.hpp:427-429
 	// (pixel, bucket) is unique within a batch and batches are stream-ordered: plain read-modify-write, no atomics,
 	// and each bucket sees its adds in accumulation order exactly like the reference.
@@ -918,14 +920,28 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	wave_sum(c_drop, &ctr->dropped);
 }
 
-// In-order merge of one batch's contribution buffer into the accumulator (see launch_batch in mirt_capi.hip): exactly the
-// `output_color[px] += radiance` of Renderer.hpp:427-429, one add per (pixel, bucket) per Accumulate() call, applied in
-// accumulation order; entries the batch did not touch hold +0 and leave the accumulator unchanged.
-__global__ __launch_bounds__(kBlock) void k_merge_contrib(float4* __restrict__ accum, const float4* __restrict__ contrib, size_t n4) {
-	for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * kBlock) {
-		float4 a = accum[i]; const float4 c = contrib[i];
-		a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
-		accum[i] = a;
+// In-order merge of one batch's contribution buffer ([tile][slot][rgb][256], slot = accumulation index inside the batch)
+// into the accumulator (see launch_batch in mirt_capi.hip): exactly the `output_color[px] += radiance` of
+// Renderer.hpp:427-429, one add per (pixel, bucket) per Accumulate() call.  Accumulation acc_base+k+1 lands in bucket
+// (acc_base+k+1) % buckets (Renderer.hpp:82); each accumulator word is owned by one thread, which applies that bucket's
+// contributions in ascending k, i.e. in accumulation order.  Entries a path did not touch hold +0 (exact no-op).
+__global__ __launch_bounds__(kBlock) void k_merge_contrib(float4* __restrict__ accum, const float4* __restrict__ contrib, uint32_t n_tiles, uint32_t buckets,
+                                                          uint32_t batch_n, uint32_t acc_base) {
+	constexpr uint32_t kQuads = 3u * kTileSize / 4u;                            // float4 per (tile, bucket)
+	const size_t n_items = static_cast<size_t>(n_tiles) * kQuads;
+	const uint32_t first = min(buckets, batch_n);
+	for (size_t item = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; item < n_items; item += static_cast<size_t>(gridDim.x) * kBlock) {
+		const size_t tile = item / kQuads; const uint32_t q = static_cast<uint32_t>(item % kQuads);
+		for (uint32_t k0 = 0; k0 < first; k0++) {
+			const uint32_t bucket = (acc_base + k0 + 1u) % buckets;
+			float4* dst = accum + (tile * buckets + bucket) * kQuads + q;
+			float4 a = *dst;
+			for (uint32_t k = k0; k < batch_n; k += buckets) {
+				const float4 c = contrib[(tile * batch_n + k) * kQuads + q];
+				a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+			}
+			*dst = a;
+		}
 	}
 }
 

@@ -114,11 +114,21 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 }
 #define HIP_TRY(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
 
+// Accumulations traced together as one batch.  A trace launch ends in a ~0.2 ms tail while its longest rays finish, so
+// launches want to be large: by default a batch carries about 32 M primary rays (cfg2: 32 accumulations of 1024^2),
+// at most kMaxBatch (the path id keeps the slot in 7 bits).
+constexpr uint32_t kMaxBatch = 64;
+constexpr uint64_t kBatchRays = 32ull << 20;
 uint32_t batch_limit(const mirt_ctx* c) {
-	uint32_t b = c->policy.buckets;
-	if (c->policy.max_batch && c->policy.max_batch < b) b = c->policy.max_batch;
-	return b ? b : 1;
+	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
+	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
+	if (n_pix == 0) return 1;
+	const uint64_t b = (kBatchRays + n_pix / 2) / n_pix;
+	return static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(b, 1), kMaxBatch));
 }
+// Paths add straight into the accumulator only when a batch cannot touch a (pixel, bucket) word twice and no other
+// batch is in flight; otherwise every batch adds into its own contribution buffer, merged in accumulation order.
+bool uses_contrib(const mirt_ctx* c, uint32_t n_slots) { return n_slots > 1 || batch_limit(c) > c->policy.buckets; }
 
 uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
 	uint64_t blocks = (work_items + kBlock - 1) / kBlock;
@@ -165,8 +175,9 @@ int ensure_streams(mirt_ctx* c) {
 	const uint32_t cap = static_cast<uint32_t>(cap64);
 	const uint32_t nb = c->policy.max_bounces;
 	const uint32_t want = wanted_slots(c);
-	const size_t acc_bytes = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize * sizeof(float);
-	if (cap == c->capacity && nb == c->arena_bounces && c->slots.size() == want && (want == 1 || c->slots[0].contrib.bytes >= acc_bytes)) return MIRT_OK;
+	const bool contrib = uses_contrib(c, want);
+	const size_t acc_bytes = static_cast<size_t>(c->n_tiles) * batch_limit(c) * 3 * kTileSize * sizeof(float);     // contribution buffer: [tile][slot][rgb][256]
+	if (cap == c->capacity && nb == c->arena_bounces && c->slots.size() == want && (!contrib || c->slots[0].contrib.bytes >= acc_bytes)) return MIRT_OK;
 	HIP_TRY(c, sync_all(c));
 	while (c->slots.size() > want) {
 		PipeSlot& sl = c->slots.back();
@@ -190,7 +201,7 @@ int ensure_streams(mirt_ctx* c) {
 		HIP_TRY(c, sl.arena.ensure(planes * plane_bytes));
 		HIP_TRY(c, sl.counts.ensure((static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t)));
 		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
-		if (want > 1) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
+		if (contrib) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
 		char* p = sl.arena.as<char>();
 		auto take = [&]() { void* r = p; p += plane_bytes; return r; };
 		for (int b = 0; b < 2; b++) {
@@ -262,6 +273,8 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	fp.n_pix = c->n_tiles * kTileSize;
 	fp.acc_base = acc_base;
 	fp.batch_n = batch_n;
+	fp.idx_base = acc_base;
+	fp.idx_buckets = c->policy.buckets;
 	fp.max_bounces = c->policy.max_bounces;
 	fp.buckets = c->policy.buckets;
 	fp.n_lights = c->scene.n_lights;
@@ -269,23 +282,25 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	return fp;
 }
 
-// One batch = up to `buckets` consecutive Accumulate() calls in flight together; consecutive accumulation indices land
-// in distinct buckets (Renderer.hpp:82), so no two paths of a batch touch the same accumulator word.
-//
-// Batches themselves are independent except for the ORDER of their adds into a bucket, so up to policy.streams of them
-// run concurrently, each on its own HIP stream with its own ray streams: every trace launch ends in a tail while its
-// longest rays finish (~0.2 ms with most of the chip idle), and late bounces are thin; a second and third batch fill
-// those holes (+49 % throughput with 3 streams on cfg2).  To keep the reference's add order each in-flight batch adds
-// into a zeroed contribution buffer, and the buffers are merged into the accumulator on the main stream in batch order.
+// One batch = up to batch_limit() consecutive Accumulate() calls traced together (path id = (slot << 24) | pixel).
+// Consecutive accumulation indices land in buckets (acc % buckets, Renderer.hpp:82), and the ORDER of the adds into a
+// bucket word is part of the result.  With at most `buckets` accumulations per batch and one batch at a time every
+// (pixel, bucket) word is touched once per batch and paths add straight into the accumulator.  Otherwise each batch adds
+// into a zeroed contribution buffer [tile][slot][rgb][256] and k_merge_contrib, enqueued on the main stream in batch
+// order, applies the slots to their buckets in ascending order — so larger batches (launches several times longer than
+// their tails) and up to policy.streams batches in flight on their own HIP streams (other batches fill those tails)
+// leave every bucket's add order, hence the result, exactly as in the reference.
 int launch_batch(mirt_ctx* c, uint32_t batch_n) {
-	const FrameParams fp = frame_params(c, c->accumulations, batch_n);
+	FrameParams fp = frame_params(c, c->accumulations, batch_n);
 	const uint32_t nb = c->policy.max_bounces;
 	const uint64_t total = static_cast<uint64_t>(fp.n_pix) * batch_n;
 	if (total == 0) return MIRT_OK;
 	const bool pipelined = c->slots.size() > 1;
 	PipeSlot& sl = c->slots[c->batch_seq % c->slots.size()];
 	hipStream_t st = pipelined ? sl.stream : c->stream;
-	const size_t acc_floats = static_cast<size_t>(c->n_tiles) * c->policy.buckets * 3 * kTileSize;
+	const bool contrib = uses_contrib(c, static_cast<uint32_t>(c->slots.size()));
+	const size_t contrib_floats = static_cast<size_t>(c->n_tiles) * batch_n * 3 * kTileSize;     // [tile][slot][rgb][256]
+	if (contrib) { fp.idx_base = 0xffffffffu; fp.idx_buckets = batch_n; }            // bucket of slot k inside the buffer = k
 	uint32_t* stream_count = sl.counts.as<uint32_t>();
 	uint32_t* shadow_count = stream_count + nb + 1;
 	uint32_t* work_next = shadow_count + nb;            // per-launch work counters of the persistent trace kernels
@@ -294,7 +309,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	uint32_t* fat_n_shadow = fat_n_closest + nb;
 	const uint32_t* zero_count = fat_n_shadow + nb;     // an always-zero count ("no shadow rays pending")
 	DevCounters* ctr = c->counters.as<DevCounters>();
-	float* accum = pipelined ? sl.contrib.as<float>() : c->accumulator.as<float>();
+	float* accum = contrib ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
 	sc.use_bvh = c->policy.use_bvh;
 	const bool count = c->policy.count_traffic != 0;
@@ -303,10 +318,8 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
 	const uint32_t tlds = trace_lds(c);
 
-	if (pipelined) {
-		if (sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));      // the slot's previous batch has been merged: buffers are free
-		HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, acc_floats * sizeof(float), st));
-	}
+	if (pipelined && sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));   // the slot's previous batch has been merged: buffers are free
+	if (contrib) HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, contrib_floats * sizeof(float), st));
 	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t), st));
 	{ Bracket t(c, MIRT_K_RAYGEN, st);
 	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, st, fp, sl.stream_buf[0], stream_count); }
@@ -320,7 +333,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.acc_base, fp.buckets, nullptr };
+		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.idx_base, fp.idx_buckets, nullptr };
 		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
 		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
 		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
@@ -334,15 +347,17 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
 	}
 	HIP_TRY(c, hipGetLastError());
-	if (pipelined) {
+	if (contrib) {
 		// merges are enqueued on the main stream in batch order => every bucket receives its adds in accumulation order
-		HIP_TRY(c, hipEventRecord(sl.batch_done, st));
-		HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.batch_done, 0));
+		if (pipelined) {
+			HIP_TRY(c, hipEventRecord(sl.batch_done, st));
+			HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.batch_done, 0));
+		}
 		{ Bracket t(c, MIRT_K_RESOLVE);
-		  hipLaunchKernelGGL(k_merge_contrib, dim3(grid_for(c, acc_floats / 4)), dim3(kBlock), 0, c->stream, c->accumulator.as<float4>(), sl.contrib.as<float4>(), acc_floats / 4); }
+		  hipLaunchKernelGGL(k_merge_contrib, dim3(grid_for(c, static_cast<uint64_t>(c->n_tiles) * (3u * kTileSize / 4u))), dim3(kBlock), 0, c->stream,
+		                     c->accumulator.as<float4>(), sl.contrib.as<float4>(), c->n_tiles, c->policy.buckets, batch_n, fp.acc_base); }
 		HIP_TRY(c, hipGetLastError());
-		HIP_TRY(c, hipEventRecord(sl.merged, c->stream));
-		sl.in_use = true;
+		if (pipelined) { HIP_TRY(c, hipEventRecord(sl.merged, c->stream)); sl.in_use = true; }
 	}
 	c->batch_seq++;
 	c->accumulations += batch_n;
