@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+LDS_PEAK_GBPS = 150000.0        # MI355X_MICROARCH.md §LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
 
 
 def algorithmic_bytes(c):
@@ -211,6 +212,13 @@ def main():
             if counts:
                 ab = algorithmic_bytes(counts)
                 ach = ab / (tr["ms"] * 1e-3) / 1e9
+                lds_bytes = 32.0 * (counts["nodes"] + counts["spheres"] + counts["shadow_nodes"] + counts["shadow_spheres"])
+                roofline["note"] = ("SURVEY.md §8d prices every BVH child box and sphere fetched at 32 B against HBM; k_trace serves them from the tree it stages "
+                                    "in LDS once per launch, so `achieved` can exceed the HBM peak: frac > 1 means HBM does not bound this kernel. Its real HBM "
+                                    "bytes per launch are `traffic` (PMC); the box/sphere part of the algorithmic bytes against the LDS roof is `lds`; the kernel "
+                                    "is bound by VALU issue and dependent LDS latency (DESIGN.md §4)")
+                roofline["lds"] = {"achieved": lds_bytes / (tr["ms"] * 1e-3) / 1e9, "peak": LDS_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": lds_bytes / (tr["ms"] * 1e-3) / 1e9 / LDS_PEAK_GBPS}
                 roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_launch=ab / tr["launches"],
                                 nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"],
                                 nodes_per_shadow_ray=counts["shadow_nodes"] / max(counts["shadow_rays"], 1))
@@ -233,7 +241,8 @@ def main():
             "config": {"workload": "cfg2: S(1000) spheres + SAH BVH, MIS, Policy.max_bounces=5 (primary+4 bounces), "
                                    f"{spp} accumulations/step, 1024x1024 px per GPU", "image": f"{width}x{height}",
                        "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
-                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU", "batches_in_flight": n_streams},
+                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU", "batches_in_flight": n_streams,
+                       "accumulations_per_batch": min(r.get_policy()["max_batch"], spp)},
             "rays_per_step": rays_total / K,
             "shadow_rays_per_step": (counts["shadow_rays"] / K) if counts else None,
             "kernel_ms_per_step": {k: v["ms"] / K for k, v in (ktimes_serial or ktimes).items() if v["launches"]},

@@ -183,6 +183,12 @@ class Renderer:
         except Exception:
             pass
 
+    def get_policy(self) -> dict:
+        """The policy in effect (max_batch / streams resolved where they were left at 0 = auto)."""
+        p = Policy()
+        self._check(self._lib.mirt_get_policy(self._ctx, C.byref(p)))
+        return {name: int(getattr(p, name)) for name, _ in Policy._fields_ if not name.startswith("_")}
+
     def set_policy(self, **kw):
         for k, v in kw.items():
             setattr(self.policy, k, int(v))

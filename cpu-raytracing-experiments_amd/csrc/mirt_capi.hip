@@ -548,7 +548,13 @@ int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
 	if (realloc_acc && c->n_tiles) { int r = alloc_accumulator(c); if (r) return r; }
 	return MIRT_OK;
 }
-int mirt_get_policy(const mirt_ctx* c, mirt_policy* p) { if (!c || !p) return MIRT_ERR_ARG; *p = c->policy; return MIRT_OK; }
+int mirt_get_policy(const mirt_ctx* c, mirt_policy* p) {
+	if (!c || !p) return MIRT_ERR_ARG;
+	*p = c->policy;
+	p->max_batch = batch_limit(c);                 // the values in effect where the caller left 0 = auto
+	p->streams = wanted_slots(c);
+	return MIRT_OK;
+}
 
 int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
 	if (!c) return MIRT_ERR_ARG;

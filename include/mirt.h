@@ -136,7 +136,7 @@ int mirt_set_camera(mirt_ctx* ctx, const float pos[3], const float orient_xyzw[4
                     float half_width, float half_height, float z, float exposure);
 
 int mirt_set_policy(mirt_ctx* ctx, const mirt_policy* policy);
-int mirt_get_policy(const mirt_ctx* ctx, mirt_policy* policy);
+int mirt_get_policy(const mirt_ctx* ctx, mirt_policy* policy);   /* with the values in effect for max_batch / streams left at 0 */
 
 /* Renderer::Resize, Renderer.hpp:53-63: h_tiles = w/16, v_tiles = h/16 (truncating), allocates and zeroes
  * the accumulator, accumulations = 0.  Owns all tiles until mirt_set_tile_range says otherwise. */

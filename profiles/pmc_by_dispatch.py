@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-dispatch view of two rocprofv3 --pmc passes (p1: SQ_WAVES.. p2: LDS/VMEM..): lane utilisation, wait share, LDS conflicts."""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 root = sys.argv[1]
 def load(f):
     rows = collections.defaultdict(dict)
@@ -14,7 +14,7 @@ def load(f):
     for (_, k), d in sorted(rows.items()):
         out[(seen[k], k)] = d; seen[k] += 1
     return out
-r1 = load(glob.glob(f"{root}/p1/*/*_counter_collection.csv")[0]); r2 = load(glob.glob(f"{root}/p2/*/*_counter_collection.csv")[0])
+r1 = load(max(glob.glob(f"{root}/p1/*/*_counter_collection.csv"), key=os.path.getmtime)); r2 = load(max(glob.glob(f"{root}/p2/*/*_counter_collection.csv"), key=os.path.getmtime))
 pat = sys.argv[2] if len(sys.argv) > 2 else "trace"
 for (i, k), d in sorted(r1.items()):
     if pat not in k: continue

@@ -5,15 +5,15 @@ dst = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01"
 src = "gpurun_out/final"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"{dst}/bench.json")
-shutil.copy(glob.glob(f"{src}/kt_serial/*/*_kernel_stats.csv")[0], f"{dst}/kernel_stats_streams1.csv")
-shutil.copy(glob.glob(f"{src}/kt_pipe/*/*_kernel_stats.csv")[0], f"{dst}/kernel_stats_streams3.csv")
+shutil.copy(max(glob.glob(f"{src}/kt_serial/*/*_kernel_stats.csv"), key=os.path.getmtime), f"{dst}/kernel_stats_streams1.csv")
+shutil.copy(max(glob.glob(f"{src}/kt_pipe/*/*_kernel_stats.csv"), key=os.path.getmtime), f"{dst}/kernel_stats_streams3.csv")
 shutil.copy(f"{src}/bench_serial_rocprof.json", f"{dst}/bench_under_rocprof_streams1.json")
-out = {"note": "rocprofv3 --pmc passes (separate runs, one counter each) of `python3 bench.py --steps 1 --warmup 0 --spp 5 --streams 1 --no-cpu-baseline --no-counts` "
-               "(one batch of 5 accumulations, 1024x1024, S(1000)). sum_KB are KB summed over the launches as rocprofv3 reports them; "
+out = {"note": "rocprofv3 --pmc passes (separate runs, one counter each) of `python3 bench.py --steps 1 --warmup 0 --spp 32 --streams 1 --no-cpu-baseline --no-counts` "
+               "(one batch of 32 accumulations, 1024x1024, S(1000): the launch sizes of the default bench run). sum_KB are KB summed over the launches as rocprofv3 reports them; "
                "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024/launches, the gfx950 correction of MI355X_MICROARCH.md §HBM (FETCH_SIZE reports half of wide coalesced reads).", "kernels": {}}
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for name in ("pmc_fetch", "pmc_write"):
-    f = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(f"{src}/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         a = agg[k][row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
