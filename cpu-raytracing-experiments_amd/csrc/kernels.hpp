@@ -326,6 +326,16 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
 	}
 	if (COUNT) n_nodes += 2;
+	// The sphere of the first leaf child is requested BEFORE the slab tests (its index comes with the record), so the second
+	// LDS round trip of the step overlaps the ~40 VALU instructions of the two box tests instead of following them.
+	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
+	const uint32_t cand = leaf_a ? c0 : c1;
+	const bool any_leaf = __ballot(leaf_a | leaf_b) != 0ull;
+	float4 s_pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (any_leaf) {
+		const uint32_t idx = (leaf_a | leaf_b) ? (cand & 0xffffffu) : 0u;     // lanes without a leaf child read sphere 0 (always valid: a leaf exists)
+		if (ALL_LDS || idx < sc.lds_spheres) s_pre = to_float4(lds.spheres[idx]); else s_pre = sc.spheres[idx];
+	}
 	const RaySlab& rs = t.rs;
 	float ta, tb;
 	bool ha = slab_hit(rs, __builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
@@ -336,9 +346,8 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	                   __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
 
 	// ---- hit leaf children are intersected at once, child 0 before child 1 (same per-ray order as the oracle's twin) ----
-	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
 	const bool la = ha & leaf_a, lb = hb & leaf_b;
-	if (__ballot(la | lb) != 0ull) {                              // wave-uniform guard: scalar branch, no exec-mask bookkeeping
+	if (any_leaf && __ballot(la | lb) != 0ull) {                  // wave-uniform guard: scalar branch, no exec-mask bookkeeping
 		// first queued leaf of this lane = child 0 if it is a hit leaf, else child 1; a second one only when both are
 		uint32_t l0 = la ? c0 : c1;
 		bool on = la | lb;
@@ -347,9 +356,14 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			if (pass == 1 && __ballot(second) == 0ull) break;
 			if (pass == 1) { l0 = c1; on = second; }
 			const uint32_t first = l0 & 0xffffffu;
-			const uint32_t idx = on ? first : 0u;                   // idle lanes read sphere 0 (always valid: a leaf exists)
-			float4 s;
-			if (ALL_LDS || idx < sc.lds_spheres) s = to_float4(lds.spheres[idx]); else s = sc.spheres[idx];
+			float4 s = s_pre;
+			const bool fetch = on & (pass == 1 || l0 != cand);      // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
+			if (__ballot(fetch) != 0ull) {
+				const uint32_t idx = fetch ? first : 0u;
+				float4 s2;
+				if (ALL_LDS || idx < sc.lds_spheres) s2 = to_float4(lds.spheres[idx]); else s2 = sc.spheres[idx];
+				s = fetch ? s2 : s_pre;
+			}
 			if (COUNT) n_spheres += on ? 1u : 0u;
 			if (ANYHIT) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
 			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
@@ -605,7 +619,7 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 // Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
 // 8 waves/SIMD (= two 16-wave workgroups per CU, the LDS plan of the binary16 layout) caps the kernel at 64 VGPRs.
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(SceneDev sc,
+__global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                        const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
                                                        ShadowBuf sh, ShadowSink sink,
