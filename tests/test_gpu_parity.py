@@ -260,10 +260,29 @@ def test_batching_and_call_splitting_do_not_change_results(mirt):
     for n in (1, 4, 0, 8):
         b.Accumulate(n)
     assert a.accumulations == b.accumulations == 13
-    assert_same(b.accumulator(), a.accumulator(), "batch 1 vs batch 5")
+    assert_same(b.accumulator(), a.accumulator(), "batch 1 vs default batch")
     assert not a.Render()                                  # 13 % 5 != 0
     a.Accumulate(2); assert a.Render()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_batches_larger_than_the_bucket_count(mirt, streams):
+    """A batch may carry more accumulations than there are buckets (default: about 32 M primary rays per batch): paths add
+    into a per-slot contribution buffer and the merge applies the slots to their buckets in accumulation order, so every
+    batch size gives the oracle's accumulator bit for bit — including sizes that do not divide the bucket count or the call."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(192, 96); o.Accumulate(23)
+    want, wc = o.accumulator(), o.counters()
+    for max_batch in (0, 1, 3, 5, 7, 16, 64):
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, streams=streams, max_batch=max_batch); r.Resize(192, 96)
+        eff = r.get_policy()
+        assert eff["max_batch"] == (max_batch or 64) and eff["streams"] == streams      # 0 = auto: 32 M rays / 18 k pixels, capped at 64
+        r.Accumulate(9); r.Accumulate(14)
+        assert_same(r.accumulator(), want, f"max_batch={max_batch} streams={streams}")
+        c = r.counters()
+        assert c["rays"] == wc["rays"] and c["terminated"] == wc["terminated"] and c["terminated"] + c["dropped"] == 23 * 192 * 96   # every path accounted for
+        r.close()
 
 
 def test_stream_pipelining_does_not_change_results(mirt):
