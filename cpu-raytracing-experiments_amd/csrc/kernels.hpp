@@ -330,9 +330,11 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	// LDS round trip of the step overlaps the ~40 VALU instructions of the two box tests instead of following them.
 	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
 	const uint32_t cand = leaf_a ? c0 : c1;
+	// (Only when the spheres are staged in LDS: from L2 the speculative packets of leaves whose box is then missed cost more
+	// than the overlap gains.)
 	const bool any_leaf = __ballot(leaf_a | leaf_b) != 0ull;
 	float4 s_pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	if (any_leaf) {
+	if (ALL_LDS && any_leaf) {
 		const uint32_t idx = (leaf_a | leaf_b) ? (cand & 0xffffffu) : 0u;     // lanes without a leaf child read sphere 0 (always valid: a leaf exists)
 		if (ALL_LDS || idx < sc.lds_spheres) s_pre = to_float4(lds.spheres[idx]); else s_pre = sc.spheres[idx];
 	}
@@ -357,7 +359,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			if (pass == 1) { l0 = c1; on = second; }
 			const uint32_t first = l0 & 0xffffffu;
 			float4 s = s_pre;
-			const bool fetch = on & (pass == 1 || l0 != cand);      // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
+			const bool fetch = on & (!ALL_LDS || pass == 1 || l0 != cand);   // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
 			if (__ballot(fetch) != 0ull) {
 				const uint32_t idx = fetch ? first : 0u;
 				float4 s2;

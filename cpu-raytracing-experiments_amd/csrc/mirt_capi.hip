@@ -123,7 +123,8 @@ uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
 	if (n_pix == 0) return 1;
-	const uint64_t b = (kBatchRays + n_pix / 2) / n_pix;
+	// large images: still at least the reference's natural group of 5 (84 M rays at 4096^2 — deep trees have longer tails)
+	const uint64_t b = std::max<uint64_t>((kBatchRays + n_pix / 2) / n_pix, std::min<uint32_t>(c->policy.buckets, 5u));
 	return static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(b, 1), kMaxBatch));
 }
 // Paths add straight into the accumulator only when a batch cannot touch a (pixel, bucket) word twice and no other
