@@ -304,10 +304,10 @@ static inline Box box_empty() { return { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_M
 static inline void box_or(Box& a, const Box& b) {                             // :35-39 (glm::min/max(vec3))
 	for (int i = 0; i < 3; i++) { a.mn[i] = glm_min(a.mn[i], b.mn[i]); a.mx[i] = glm_max(a.mx[i], b.mx[i]); }
 }
-static bool g_experiment_true_area = false;   // true while building the mode-2 internal tree: full half area instead of the reference's Q15 formula
+static bool g_true_half_area = false;   // true while building the mode-2 internal tree: full half area instead of the reference's Q15 formula
 static inline float box_half_area(const Box& b) {                             // :58-67 — Q15: only d.y*d.z
 	float d[3] = { b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2] };
-	if (g_experiment_true_area) return (d[0] * d[1] + d[1] * d[2]) + d[2] * d[0];      // csrc/bvh_build.cpp sah_area(full)
+	if (g_true_half_area) return (d[0] * d[1] + d[1] * d[2]) + d[2] * d[0];      // csrc/bvh_build.cpp sah_area(full)
 	float area = 0.0f;
 	int32_t i = 2;
 	for (float accum = d[i--]; i > 0; i--) { area += d[i] * accum; accum += d[i]; }
@@ -850,7 +850,7 @@ struct Oracle {
 	Counters counters;
 };
 
-// experiment: histogram of |D|^2 - 1 over all rays handed to traverse() (orc_len_hist)
+// diagnostic (DESIGN.md "Traversal semantics"): histogram of |D|^2 - 1 over all rays handed to traverse() (orc_len_hist)
 static std::atomic<uint64_t> g_len_hist[16];
 static bool g_len_hist_on = false;
 static void traverse(const Oracle& o, const Buffer& in, Hit& out, size_t size, LocalCounters& lc) {
@@ -1173,10 +1173,10 @@ static int render(const Oracle& o, float* rgba) {
 static void build_accel(Oracle& o) {
 	o.accel = BVH{};
 	if (o.accel_internal) {
-		g_experiment_true_area = true;
+		g_true_half_area = true;
 		BVH tmp; std::vector<uint32_t> order;
 		bvh_build(o.bvh.prims, tmp, &order);
-		g_experiment_true_area = false;
+		g_true_half_area = false;
 		o.accel.nodes = tmp.nodes; o.accel.slot_prim = order;
 	} else {
 		o.accel.nodes = o.bvh.nodes;
