@@ -140,8 +140,8 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(K):
-        r.Accumulate(spp)              # synchronous: returns after the context's stream has drained
-    sync_all()
+        r.AccumulateAsync(spp)         # one step = one 64-accumulation call, enqueued like the reference's frame loop; the K steps are
+    sync_all()                         # bracketed by device synchronisation on both sides, not separated by it
     elapsed = time.perf_counter() - t0
     ktimes = r.kernel_times(reset=True)
     if dist is not None:
