@@ -596,18 +596,22 @@ MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, floa
 // ray, straight into the next stream's radiance planes or the accumulator: k_trace is VALU-bound, so the ~16 memory
 // instructions per shadow ray ride along for free, where a separate pass over the shadow stream cost 4.8 ms per cfg2 step.
 // occ != nullptr (mirt_debug_trace_shadow): only the occlusion flag is stored.
+constexpr uint32_t kDestHasE = 0x40000000u;     // shadow record carries an emissive add (else it is +0 and the planes are not touched)
 struct ShadowSink {
 	float *rr, *rg, *rb;        // radiance planes of the stream k_shade reads next
 	float* accum;
 	uint32_t acc_base, buckets;
 	uint32_t* occ;
+	uint32_t r_zero;            // shadow rays of bounce 0: the path radiance before the bounce is +0 and is not stored
 };
 MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t i, bool occluded, uint32_t& c_term) {
 	if (sink.occ) { sink.occ[i] = occluded ? 1u : 0u; return; }
-	f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
+	const uint32_t dest_word = sh.dest[i];
+	f3 R{ 0.0f, 0.0f, 0.0f }, E{ 0.0f, 0.0f, 0.0f };
+	if (!sink.r_zero) R = { sh.rr[i], sh.rg[i], sh.rb[i] };
 	const f3 S{ sh.sr[i], sh.sg[i], sh.sb[i] };
-	const f3 E{ sh.er[i], sh.eg[i], sh.eb[i] };
-	const uint32_t dest = sh.dest[i];
+	if (dest_word & kDestHasE) E = { sh.er[i], sh.eg[i], sh.eb[i] };
+	const uint32_t dest = dest_word & ~kDestHasE;
 	R.x = occluded ? R.x : R.x + S.x; R.y = occluded ? R.y : R.y + S.y; R.z = occluded ? R.z : R.z + S.z;
 	R.x += E.x; R.y += E.y; R.z += E.z;
 	if (dest & kDestAccum) { c_term++; accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), R.x, R.y, R.z); }
@@ -800,16 +804,17 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		}
 		// ---- regroup: the closest-hit shader is ~800 VALU instructions per ray and only 40-60 % of a secondary stream hits;
 		// packing the hits of the block into its first waves runs that code on full waves (lane utilisation 0.42 -> ~0.9) ----
-		const uint32_t n_hits = block_compact(is_hit, base + threadIdx.x, compact_scratch, hit_list);
+		// (Not for primary rays: ~95 % of them hit, the stream is already dense, and the two barriers cost more than they save.)
+		const uint32_t n_hits = FIRST ? 0u : block_compact(is_hit, base + threadIdx.x, compact_scratch, hit_list);
 
 		// ---- phase 2, one lane per hit ----
-		bool survive = false, has_shadow = false, terminated = false;
+		bool survive = false, has_shadow = false, terminated = false, has_E = false;
 		uint32_t path = 0;
 		f3 P{0, 0, 0}, ndir{0, 0, 0}, L{0, 0, 0}, srad{0, 0, 0}, E{0, 0, 0};
 		f3 R{0.0f, 0.0f, 0.0f}, thr{1.0f, 1.0f, 1.0f};
 		float npdf = 0.0f, light_distance = 0.0f;
-		if (threadIdx.x < n_hits) {
-			const uint32_t i = hit_list[threadIdx.x];
+		if (FIRST ? is_hit : threadIdx.x < n_hits) {
+			const uint32_t i = FIRST ? base + threadIdx.x : hit_list[threadIdx.x];
 			path = in.path[i];
 			const f3 D{ in.dx[i], in.dy[i], in.dz[i] };
 			float pdf_in = 0.0f;
@@ -876,6 +881,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 					} while (false);
 				}
 				// EMISSIVE PRIMITIVE HIT, Renderer.hpp:319-353
+				has_E = is_emissive;
 				if (is_emissive) {
 					if (fp.mis && bounce > 0) {
 						const float radius2 = hs.w;
@@ -922,9 +928,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			sh.dx[sslot] = L.x; sh.dy[sslot] = L.y; sh.dz[sslot] = L.z;
 			sh.tfar[sslot] = light_distance;
 			sh.sr[sslot] = srad.x; sh.sg[sslot] = srad.y; sh.sb[sslot] = srad.z;
-			sh.rr[sslot] = R.x; sh.rg[sslot] = R.y; sh.rb[sslot] = R.z;
-			sh.er[sslot] = E.x; sh.eg[sslot] = E.y; sh.eb[sslot] = E.z;
-			sh.dest[sslot] = survive ? slot : (kDestAccum | path);
+			if (!FIRST) { sh.rr[sslot] = R.x; sh.rg[sslot] = R.y; sh.rb[sslot] = R.z; }      // bounce 0: R is +0 (ShadowSink::r_zero)
+			if (has_E) { sh.er[sslot] = E.x; sh.eg[sslot] = E.y; sh.eb[sslot] = E.z; }       // else +0: not stored (kDestHasE clear)
+			sh.dest[sslot] = (survive ? slot : (kDestAccum | path)) | (has_E ? kDestHasE : 0u);
 		} else if (survive || terminated) {
 			const f3 Rf{ R.x + E.x, R.y + E.y, R.z + E.z };                       // E is +0 when the hit is not emissive (exact no-op)
 			if (survive) { out.rr[slot] = Rf.x; out.rg[slot] = Rf.y; out.rb[slot] = Rf.z; }

@@ -117,7 +117,7 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 // Accumulations traced together as one batch.  A trace launch ends in a ~0.2 ms tail while its longest rays finish, so
 // launches want to be large: by default a batch carries about 32 M primary rays (cfg2: 32 accumulations of 1024^2),
 // at most kMaxBatch (the path id keeps the slot in 7 bits).
-constexpr uint32_t kMaxBatch = 64;
+constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestHasE)
 constexpr uint64_t kBatchRays = 32ull << 20;
 uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
@@ -334,7 +334,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.idx_base, fp.idx_buckets, nullptr };
+		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.idx_base, fp.idx_buckets, nullptr, bounce == 1 ? 1u : 0u };
 		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
 		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
 		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
