@@ -416,7 +416,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 // kRefillIdle lanes are idle they are given the next rays of the window — slot = wbeg + rank among idle lanes, from a
 // wave64 ballot + mbcnt prefix sum — and the wave goes back to stepping all lanes together.
 constexpr uint32_t kChunkMax = 512;
-constexpr uint32_t kRefillIdle = 16;
+constexpr uint32_t kRefillIdle = 32;   // measured on cfg2: 8 -> 15.3 ms of trace per step, 16 -> 13.9, 24..40 -> 13.5 (a refill runs the ~200-instruction ray set-up on the whole wave)
 constexpr uint32_t kNone = 0xffffffffu;
 struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
 struct WaveWindow { uint32_t beg, end, chunk; bool more; };
