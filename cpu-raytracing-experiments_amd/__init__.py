@@ -35,7 +35,7 @@ class Policy(C.Structure):
     """mirt_policy — RendererPolicy (Renderer.hpp:19-26) + the path's compile-time switches."""
     _fields_ = [("max_bounces", C.c_uint32), ("buckets", C.c_uint32), ("mis", C.c_uint32), ("use_bvh", C.c_uint32),
                 ("count_traffic", C.c_uint32), ("profile", C.c_uint32), ("max_batch", C.c_uint32), ("reference_tree", C.c_uint32),
-                ("streams", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+                ("streams", C.c_uint32), ("gpu_build", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
 
 
 class Counters(C.Structure):
@@ -152,7 +152,7 @@ class Renderer:
 
     def __init__(self, scene: Scene, device: int = 0, max_bounces: int = 16, buckets: int = 5, mis: bool = True,
                  use_bvh: bool = False, count_traffic: bool = False, profile: bool = False, max_batch: int = 0,
-                 allow_half_boxes: bool = True, reference_tree: bool = False, streams: int = 0):
+                 allow_half_boxes: bool = True, reference_tree: bool = False, streams: int = 0, gpu_build: bool = False):
         self._lib = load_library()
         self._ctx = C.c_void_p()
         rc = self._lib.mirt_create(device, C.byref(self._ctx))
@@ -161,7 +161,7 @@ class Renderer:
         self.scene = scene
         self.width = self.height = 0
         self.framebuffer = None
-        self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), int(profile), max_batch, int(reference_tree), int(streams))
+        self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), int(profile), max_batch, int(reference_tree), int(streams), int(gpu_build))
         self._check(self._lib.mirt_set_policy(self._ctx, C.byref(self.policy)))
         self._check(self._lib.mirt_debug_allow_half_boxes(self._ctx, int(allow_half_boxes)))
         self.UpdateScene()

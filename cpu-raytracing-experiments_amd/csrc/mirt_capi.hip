@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "bvh_layout.hpp"
 #include "bvh_build.hpp"
+#include "lbvh_build.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -75,7 +76,7 @@ struct mirt_ctx {
 	hipStream_t stream = nullptr;
 	std::string error;
 
-	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, { 0, 0, 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
+	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, 0, { 0, 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t first_tile = 0, n_tiles = 0;
 	uint32_t accumulations = 0;
@@ -477,24 +478,43 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	}
 	std::memcpy(sky.data(), hdri_rgba, sky.size() * sizeof(float4));
 	std::vector<float> recs;
-	uint32_t depth = 0;
-	if (c->policy.reference_tree || n_spheres == 0) {
-		// traverse the caller's tree exactly as handed over (BVH.hpp:18-31 nodes over the BVH-order prims)
-		const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
-		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str());
-	} else {
-		// default: GPU-internal SAH tree over the same BVH-order prims (hit.primID keeps its meaning; results are identical)
-		std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
-		mirt_host::build_sah_tree(bvh_prims, n_spheres, own, prim_of_slot);
-		const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, &prim_of_slot);
-		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "internal BVH rejected: %s", why.c_str());
-	}
-	const uint32_t n_recs = static_cast<uint32_t>(recs.size() / 16);
 	std::vector<uint32_t> half_recs;
-	const bool half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
-
+	uint32_t depth = 0, n_recs = 0;
+	bool half = false;
 	int r;
-	if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs)) || (r = upload(c, c->spheres, sph)) || (r = upload(c, c->prim_mat, pm)) ||
+	if ((r = upload(c, c->spheres, sph))) return r;
+	const bool gpu_tree = c->policy.gpu_build && !c->policy.reference_tree && n_spheres >= 2;
+	if (gpu_tree) {
+		// the tree the kernels walk, built where it is used (lbvh_build.hip); binary16 records under the same conditions as on the host
+		n_recs = n_spheres - 1;
+		half = c->allow_half && n_recs <= 65535;
+		for (uint32_t i = 0; half && i < n_spheres; i++) {
+			const float rad = std::sqrt(sph[i].w);
+			const float amax = std::fmax(std::fmax(std::fabs(sph[i].x), std::fabs(sph[i].y)), std::fabs(sph[i].z)) + rad * 1.0001f;
+			if (amax > 60000.0f || 2.0f * rad < 8.0f * mirt_host::half_ulp_at(amax)) half = false;
+		}
+		HIP_TRY(c, c->recs.ensure(static_cast<size_t>(n_recs) * (half ? 32u : 64u)));
+		std::string why;
+		if (!mirt_gpu::build_lbvh(c->stream, c->spheres.as<float4>(), n_spheres, half ? nullptr : c->recs.as<float>(), half ? c->recs.as<uint32_t>() : nullptr, &depth, &why))
+			return fail(c, MIRT_ERR_HIP, "GPU BVH build: %s", why.c_str());
+		if (depth > kStack) return fail(c, MIRT_ERR_ARG, "GPU-built BVH is %u levels deep (limit %u): set policy.gpu_build = 0 for this scene", depth, kStack);
+	} else {
+		if (c->policy.reference_tree || n_spheres == 0) {
+			// traverse the caller's tree exactly as handed over (BVH.hpp:18-31 nodes over the BVH-order prims)
+			const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
+			if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str());
+		} else {
+			// default: GPU-internal SAH tree over the same BVH-order prims (hit.primID keeps its meaning; results are identical)
+			std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
+			mirt_host::build_sah_tree(bvh_prims, n_spheres, own, prim_of_slot);
+			const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, &prim_of_slot);
+			if (!why.empty()) return fail(c, MIRT_ERR_ARG, "internal BVH rejected: %s", why.c_str());
+		}
+		n_recs = static_cast<uint32_t>(recs.size() / 16);
+		half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
+		if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs))) return r;
+	}
+	if ((r = upload(c, c->prim_mat, pm)) ||
 	    (r = upload(c, c->light_sphere, lsp)) || (r = upload(c, c->light_emit, lem)) || (r = upload(c, c->mat_albedo, alb)) ||
 	    (r = upload(c, c->mat_emission, emi)) || (r = upload(c, c->hdri, sky))) return r;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));

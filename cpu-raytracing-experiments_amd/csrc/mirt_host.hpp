@@ -115,6 +115,7 @@ struct RendererPolicy {                                                    // Re
 	bool mis = true;                                                       // #define MIS true, Renderer.hpp:71
 	bool use_bvh = true;                                                   // reference ships USEBVH false (BVH.hpp:307); results are identical
 	bool reference_tree = false;                                           // true: traverse scene.acceleration_structure.nodes as is instead of the internal SAH tree
+	bool gpu_build = false;                                                // true: internal tree built on the GPU (LBVH) at SceneChanged(): faster rebuild, slower rays
 };
 
 class Renderer {
@@ -124,7 +125,7 @@ public:
 	explicit Renderer(const Scene& scene_ref, RendererPolicy policy = {}, int device = 0) : scene(scene_ref) {
 		if (mirt_create(device, &ctx_) != MIRT_OK) throw std::runtime_error(std::string("mirt_create: ") + mirt_last_error(nullptr));
 		mirt_policy p{};
-		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh; p.reference_tree = policy.reference_tree;
+		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh; p.reference_tree = policy.reference_tree; p.gpu_build = policy.gpu_build;
 		check(mirt_set_policy(ctx_, &p), "mirt_set_policy");
 	}
 	~Renderer() { if (ctx_) mirt_destroy(ctx_); }

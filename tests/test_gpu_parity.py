@@ -219,6 +219,33 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     r.close()
 
 
+@pytest.mark.parametrize("scene_name,allow_half,w,h,spp,mb", [("default9", True, 64, 64, 5, 16), ("S8a", True, 64, 64, 5, 5), ("S1000a", True, 128, 128, 5, 5),
+                                                             ("S1000a", False, 128, 128, 5, 5), ("S20000", True, 256, 128, 5, 6)])
+def test_gpu_built_tree_gives_the_same_results(mirt, scene_name, allow_half, w, h, spp, mb):
+    """policy.gpu_build: the traversal tree is built on the GPU (Morton-order LBVH, lbvh_build.hip) instead of the host SAH
+    sweep.  A different tree must not change a single bit of the result (DESIGN.md "Traversal semantics"); it only costs
+    more box tests per ray."""
+    sc = mirt.scene.synthetic(20000) if scene_name == "S20000" else make_scene(mirt, scene_name)
+    a = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, allow_half_boxes=allow_half, count_traffic=True); a.Resize(w, h); a.Accumulate(spp)
+    g = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, allow_half_boxes=allow_half, count_traffic=True, gpu_build=True); g.Resize(w, h); g.Accumulate(spp)
+    n = len(sc.geometry)
+    ia, ig = a.debug_info(), g.debug_info()
+    assert ig["records"] == n - 1 == ia["records"] and ig["half_boxes"] == ia["half_boxes"] and ig["depth"] <= 64
+    assert_same(g.accumulator(), a.accumulator(), f"{scene_name}: GPU-built tree vs host SAH tree")
+    ca, cg = a.counters(), g.counters()
+    assert cg["rays"] == ca["rays"] and cg["shadow_rays"] == ca["shadow_rays"] and cg["terminated"] == ca["terminated"]
+    assert cg["nodes"] < 4 * ca["nodes"]                         # an LBVH costs more box tests, not an order of magnitude more
+    if scene_name in ("default9", "S1000a"):
+        o = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+        assert_same(g.accumulator(), o.accumulator(), f"{scene_name}: GPU-built tree vs brute-force oracle")
+    # an edit: same context, scene handed over again -> rebuilt on the GPU
+    sc.geometry["position"][1, 1] += 0.25
+    for r in (a, g):
+        r.UpdateScene(); r.ResetAccumulator(); r.Accumulate(spp)
+    assert_same(g.accumulator(), a.accumulator(), f"{scene_name}: after an edit")
+    a.close(); g.close()
+
+
 def test_white_furnace_gpu(mirt):
     r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
     assert np.all(r.accumulator() == 1.0)
