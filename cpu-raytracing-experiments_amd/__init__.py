@@ -195,11 +195,15 @@ class Renderer:
         self._check(self._lib.mirt_set_policy(self._ctx, C.byref(self.policy)))
 
     # -- scene hand-over (Application.cpp:230-234) -------------------------------------------------
-    def UpdateScene(self):
+    def UpdateScene(self, nodes=None):
+        """Hands the scene over again (after an edit).  `nodes`: a caller-made tree over the reference-order prims instead of the
+        reference builder's (BVH.hpp:18-31 layout, children at first_id / first_id+1, leaves first_id..first_id+prim_count-1)."""
         s = self.scene
         self.geometry = np.ascontiguousarray(s.geometry, dtype=SPHERE)
         self.material = np.ascontiguousarray(s.material, dtype=MATERIAL)
         self.nodes, self.prims = bvh_build(self.geometry)
+        if nodes is not None:
+            self.nodes = np.ascontiguousarray(nodes, dtype=NODE)
         self.lights = light_list(self.geometry, self.material)
         hdri = np.ascontiguousarray(s.hdri, dtype=np.float32)
         amb = np.ascontiguousarray(s.ambient, dtype=np.float32)

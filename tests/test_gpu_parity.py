@@ -246,6 +246,44 @@ def test_gpu_built_tree_gives_the_same_results(mirt, scene_name, allow_half, w, 
     a.close(); g.close()
 
 
+def test_caller_tree_with_multi_prim_leaves(mirt):
+    """policy.reference_tree walks whatever Node[] the caller hands over.  The reference's builder only makes one-prim leaves
+    (BVH.hpp:201-205), but its traversal loops over prim_count (BVH.hpp:343-345): a hand-made tree with up to 5 prims per
+    leaf (median splits of the BVH-order range) must give the brute-force result, with binary16 and f32 records."""
+    sc = mirt.scene.synthetic(300, ambient=0.5)
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 96); o.Accumulate(5)
+    for allow_half in (True, False):
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, allow_half_boxes=allow_half, count_traffic=True)
+        prims = r.prims
+        rad = np.sqrt(prims["radius_sq"])[:, None]
+        lo, hi = prims["position"] - rad, prims["position"] + rad
+        nodes = []
+        def build(a, b):                                    # returns the index of the node covering prims [a, b)
+            i = len(nodes); nodes.append(None)
+            fill(i, a, b)
+            return i
+        def fill(i, a, b):
+            if b - a <= 5:
+                nodes[i] = (lo[a:b].min(0), a, hi[a:b].max(0), b - a)
+                return
+            m = (a + b) // 2
+            k = len(nodes); nodes.append(None); nodes.append(None)     # children adjacent: first_id, first_id + 1
+            nodes[i] = (lo[a:b].min(0), k, hi[a:b].max(0), 0)
+            fill(k, a, m); fill(k + 1, m, b)
+        build(0, len(prims))
+        arr = np.zeros(len(nodes), dtype=mirt.scene.NODE)
+        for i, (mn, first, mx, cnt) in enumerate(nodes):
+            arr[i] = (mn, first, mx, cnt)
+        assert (arr["prim_count"] > 1).any() and arr["prim_count"].max() == 5
+        r.UpdateScene(nodes=arr)
+        r.Resize(96, 96); r.Accumulate(5)
+        assert r.debug_info()["half_boxes"] == int(allow_half)
+        assert_same(r.accumulator(), o.accumulator(), f"multi-prim leaves, half={allow_half}")
+        c = r.counters()
+        assert c["spheres"] > c["rays"]                      # several prims per visited leaf
+        r.close()
+
+
 def test_white_furnace_gpu(mirt):
     r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
     assert np.all(r.accumulator() == 1.0)
