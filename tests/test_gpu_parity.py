@@ -284,6 +284,45 @@ def test_caller_tree_with_multi_prim_leaves(mirt):
         r.close()
 
 
+def _awkward_scene(mirt, seed, n):
+    """Spheres chosen to stress the tree builders and the tie rule: exact duplicates, concentric shells, a sphere around the
+    camera, tiny and huge radii side by side, many centres on one plane / one line (equal Morton codes, zero-extent axes)."""
+    S = mirt.scene
+    rng = np.random.default_rng(seed)
+    geo = np.zeros(n, dtype=S.SPHERE)
+    geo["position"] = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    geo["radius_sq"] = (rng.uniform(0.05, 1.2, n) ** 2).astype(np.float32)
+    if n >= 8:
+        geo["position"][1] = geo["position"][0]; geo["radius_sq"][1] = geo["radius_sq"][0]          # exact duplicate: equal distances, prim index decides
+        geo["position"][2] = geo["position"][0]; geo["radius_sq"][2] = geo["radius_sq"][0] * 4       # concentric shell
+        geo["position"][3] = (0.0, 1.0, 14.0); geo["radius_sq"][3] = 4.0                              # contains the camera
+        geo["radius_sq"][4] = 1e-6; geo["radius_sq"][5] = 400.0                                      # tiny / huge
+    if seed % 2:
+        geo["position"][n // 2:, 1] = 0.5                                                            # half the centres on one plane
+    if seed % 3 == 0:
+        geo["position"][n // 2:, 0] = 1.0; geo["position"][n // 2:, 1] = 0.5                         # ... on one line
+    mats = np.zeros(4, dtype=S.MATERIAL)
+    mats["albedo"][:3] = [(0.8, 0.3, 0.3), (0.3, 0.8, 0.3), (0.6, 0.6, 0.9)]
+    mats["albedo"][3] = 1.0; mats["emission"][3] = 15.0
+    geo["material_ID"] = rng.integers(0, 3, n)
+    geo["material_ID"][rng.integers(0, n, max(1, n // 16))] = 3
+    cam = S.Camera(eye=(0.0, 1.0, 14.0), direction=(0.0, -0.05, -1.0), focal_length=35.0, exposure=1.0)
+    return S.Scene(geo, mats, cam, np.full(3, 0.3, dtype=np.float32), name=f"awkward{seed}")
+
+
+@pytest.mark.parametrize("seed,n", [(1, 2), (2, 3), (3, 17), (4, 64), (5, 257), (6, 1500)])
+def test_awkward_scenes_all_tree_builders_equal_brute_force(mirt, seed, n):
+    sc = _awkward_scene(mirt, seed, n)
+    o = ob.Oracle(sc, max_bounces=6, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64); o.Accumulate(5)
+    want = o.accumulator()
+    for kw in (dict(use_bvh=False), dict(use_bvh=True), dict(use_bvh=True, reference_tree=True), dict(use_bvh=True, gpu_build=True),
+               dict(use_bvh=True, gpu_build=True, allow_half_boxes=False)):
+        r = mirt.Renderer(sc, max_bounces=6, **kw); r.Resize(96, 64); r.Accumulate(5)
+        assert_same(r.accumulator(), want, f"seed {seed} n {n} {kw}")
+        assert r.counters()["rays"] == o.counters()["rays"]
+        r.close()
+
+
 def test_white_furnace_gpu(mirt):
     r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
     assert np.all(r.accumulator() == 1.0)
