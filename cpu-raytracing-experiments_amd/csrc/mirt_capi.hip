@@ -317,7 +317,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const bool count = c->policy.count_traffic != 0;
 	const uint32_t grid = grid_for(c, total);
 	const uint32_t tgrid = trace_grid(c, total);
-	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 2u));
+	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 3u));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
 	const uint32_t tlds = trace_lds(c);
 
 	if (pipelined && sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));   // the slot's previous batch has been merged: buffers are free
