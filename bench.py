@@ -248,6 +248,14 @@ def main():
                 roofline["shade"] = {"bound": "hbm", "kernel": "k_shade", "achieved": sb / (sh["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": sb / (sh["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches": sh["launches"], "avg_launch_ms": sh["ms"] / sh["launches"],
                                      "note": "stream I/O only; the shadow-ray records it also writes (up to 68 B per NEE ray) are not in the §8d figure"}
+            if counts:
+                # all algorithmic bytes of the job (traversal + 56 B written and 56 B read per extension ray + 24 B per terminated path)
+                # over the job's wall time, against 8 TB/s per GPU
+                ext = counts["rays"] - K * spp * count * 256
+                job_bytes = algorithmic_bytes(counts) + 112.0 * ext + 24.0 * counts["terminated"]
+                roofline["whole_job"] = {"achieved": job_bytes * world / elapsed / 1e9, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                                         "frac": job_bytes / elapsed / 1e9 / HBM_PEAK_GBPS,
+                                         "note": "rank 0's algorithmic bytes x ranks over the timed pass (all kernels, batches overlapped)"}
             traffic_file = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
             if os.path.exists(traffic_file):
                 try:
