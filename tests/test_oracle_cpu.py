@@ -238,3 +238,18 @@ def test_no_cpu_fallback(mirt):
         mirt.Renderer(mirt.scene.default9())
     lib = mirt.load_library()
     assert lib.mirt_accumulate(None, 1) < 0 and lib.mirt_render(None, None) < 0
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """The product's host-side C++ (reference-order BVH builder, light list, internal SAH tree, record layout, binary16 records)
+    compiled with -fsanitize=address,undefined and run over scene sizes 1 .. 20 000, duplicates included (GPU sanitizers are
+    not available on this pool; the device code is covered by the parity tests)."""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "host_sanitize"
+    src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), os.path.join(ROOT, "cpu-raytracing-experiments_amd", "csrc", "bvh_build.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", *src, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "n=20000 nodes=39999 recs=19999" in out.stdout
