@@ -95,12 +95,12 @@ inline float half_ulp_at(float magnitude) {                // spacing of binary1
 inline uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 24) | first; }
 
 // 32-B half-precision records from the 64-B ones.  Returns false (and leaves `out` empty) when binary16 is not adequate:
-// a coordinate beyond +-60000, more than 65535 records (the u16 traversal stack), or a leaf box whose smallest extent is
-// under 8 quantisation steps (the box would grow by more than ~25 %).
+// a coordinate beyond +-60000, or a leaf box whose smallest extent is under 8 quantisation steps (the box would grow by
+// more than ~25 %).  (With more than 65535 records the traversal stack keeps u32 entries, see mirt_capi.hip.)
 inline bool build_half_records(const std::vector<float>& recs, std::vector<uint32_t>& out) {
 	out.clear();
 	const size_t n = recs.size() / 16;
-	if (n == 0 || n > 65535) return false;
+	if (n == 0) return false;
 	for (size_t r = 0; r < n; r++) {
 		const float* q = recs.data() + r * 16;
 		for (int child = 0; child < 2; child++) {

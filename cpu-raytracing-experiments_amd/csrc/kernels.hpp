@@ -27,6 +27,7 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kShadeBlock = 512;           // shade: ~80 VGPRs = 24 waves per CU = three 8-wave workgroups (1024-thread workgroups: one per CU, every barrier stalls the CU)
 constexpr uint32_t kTraceBlock = 1024;          // trace kernels: one workgroup per CU stages the BVH into LDS once per launch
 constexpr uint32_t kLdsStack = 16;              // traversal-stack entries per lane kept in LDS (deeper ones spill to scratch)
+constexpr uint32_t kLdsStackWide = 12;          // ... with binary16 records but u32 entries (> 65535 records): 48 KB, so that two workgroups still share a CU
 constexpr uint32_t kLeafBit = 0x80000000u;      // child reference flag (bvh_layout.hpp)
 constexpr uint32_t kTileSize = 256;
 constexpr uint32_t kTileRoot = 16;
@@ -45,7 +46,8 @@ struct SceneDev {
 	uint32_t n_spheres, n_recs, n_mat, n_lights;
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
-	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each) and the LDS stack holds u16 entries
+	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
+	uint32_t stack16;           // 1: record indices fit 16 bits and the LDS stack holds u16 entries (binary16 records, <= 65535 of them)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
 	float hdri_fw, hdri_fh;
@@ -278,7 +280,7 @@ struct Trav {
 };
 // Stack entries beyond the LDS-resident ones.  Kept OUTSIDE Trav: a dynamically indexed member would pin the whole struct
 // in scratch memory (every step would then reload the ray through VMEM); alone, only this rarely-touched array lives there.
-struct TravSpill { uint32_t e[kStack - kLdsStack]; };
+struct TravSpill { uint32_t e[kStack - kLdsStackWide]; };
 // Rays whose cone half-width exceeds kAlphaFat per unit of ray parameter (|D|^2 - 1 > ~1e-4: a few per million, produced
 // by the reference's ill-conditioned tangent frame) are not traversed: the inflated ray would touch most of the tree and one
 // lane would walk it serially (measured: 20-57 ms per launch on a 100k-sphere scene).  They go to a "fat ray" list and
@@ -294,7 +296,7 @@ MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float d
 // One step = one 64-B record: slab-test both children against the current tfar, intersect hit leaf children at once,
 // re-check inner children against the shrunken tfar, enter the nearer, push the other (or pop).  Returns true when this
 // ray is finished (stack empty, or ANYHIT occluder found -> occluded = true).
-template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF>
+template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
 MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres) {
 	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
 	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
@@ -390,18 +392,19 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	const bool a_first = ANYHIT ? true : (ta <= tb);
 	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one inner child is hit
 	const uint32_t far = a_first ? c1 : c0;                                   // inner reference = record index; depth < 64 is validated on the host
+	constexpr uint32_t lds_entries = (HALF && !ST16) ? kLdsStackWide : kLdsStack;
 	uint32_t sp = t.sp;
 	if (both) {
-		if (sp < kLdsStack) { if (HALF) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(far); else lds.stack[sp * lstride + threadIdx.x] = far; }
-		else if (sp < kStack) spill.e[sp - kLdsStack] = far;
+		if (sp < lds_entries) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(far); else lds.stack[sp * lstride + threadIdx.x] = far; }
+		else if (sp < kStack) spill.e[sp - lds_entries] = far;
 	}
 	sp += both ? 1u : 0u;
 	uint32_t next = near;
 	const bool pop = none & (sp != 0u);
 	if (pop) {
 		--sp;
-		if (sp < kLdsStack) next = HALF ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
-		else next = spill.e[sp - kLdsStack];
+		if (sp < lds_entries) next = ST16 ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
+		else next = spill.e[sp - lds_entries];
 	}
 	const bool finished = (ANYHIT & occluded) | (none & !pop);
 	t.sp = sp;
@@ -454,7 +457,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_
 //     ray indices of the window and loads + sets up their rays — all as batched, mostly coalesced accesses.  (An earlier
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
-template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, class LoadRay, class StoreResult>
+template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
 	WaveWindow w{ 0, 0, pick_chunk(n), true };
@@ -482,7 +485,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n,
 		const bool can_refill = work_left;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
 		for (;;) {
-			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS, HALF>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
+			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
 			const unsigned long long running = __ballot(ri != kNone && !done);
 			if (running == 0ull) break;
 			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;
@@ -568,11 +571,12 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
-		if (all) trace_persistent<ANYHIT, COUNT, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (!sc.stack16) trace_persistent<ANYHIT, COUNT, false, true, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);   // > 65535 records: never all in LDS
+		else if (all) trace_persistent<ANYHIT, COUNT, true, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	} else {
-		if (all) trace_persistent<ANYHIT, COUNT, true, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (all) trace_persistent<ANYHIT, COUNT, true, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	}
 }
 

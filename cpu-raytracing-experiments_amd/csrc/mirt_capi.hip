@@ -143,11 +143,13 @@ uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
 // Trace kernels are launched as a resident grid (as many 512-thread workgroups as their LDS footprint lets a
 // CU hold) and grid-stride over the stream, so each workgroup stages the BVH into LDS once per launch.
 constexpr uint32_t kLdsPerCu = 160u * 1024u;
-// LDS plan of a trace workgroup (1024 lanes): staged BVH bytes + a 16-entry stack per lane.  With binary16 records the
-// stack entries are u16 (32 KB) and the staged bytes are capped at 48 KB so that TWO workgroups (32 waves) share a CU;
-// with f32 records it is a u32 stack (64 KB) + up to 96 KB, one workgroup per CU.
-uint32_t stack_bytes(const mirt_ctx* c) { return kLdsStack * kTraceBlock * (c->scene.half_boxes ? 2u : 4u); }
-uint32_t stage_budget(bool half) { return half ? 48u * 1024u : 96u * 1024u; }
+// LDS plan of a trace workgroup (1024 lanes): staged BVH bytes + a per-lane traversal stack.
+//   binary16 records, <= 65535 of them: 16 u16 entries (32 KB) + up to 48 KB staged  -> TWO workgroups (32 waves) per CU
+//   binary16 records, more of them:     12 u32 entries (48 KB) + up to 32 KB staged  -> two workgroups per CU
+//   f32 records:                        16 u32 entries (64 KB) + up to 96 KB staged  -> one workgroup per CU
+uint32_t stack_bytes(bool half, bool stack16) { return half ? (stack16 ? kLdsStack * kTraceBlock * 2u : kLdsStackWide * kTraceBlock * 4u) : kLdsStack * kTraceBlock * 4u; }
+uint32_t stack_bytes(const mirt_ctx* c) { return stack_bytes(c->scene.half_boxes != 0, c->scene.stack16 != 0); }
+uint32_t stage_budget(bool half, bool stack16) { return half ? (stack16 ? 48u * 1024u : 32u * 1024u) : 96u * 1024u; }
 uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? c->trace_lds_bytes + stack_bytes(c) : kBruteChunk * 16u; }
 uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 	uint32_t per_cu = kLdsPerCu / trace_lds(c);
@@ -487,7 +489,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	if (gpu_tree) {
 		// the tree the kernels walk, built where it is used (lbvh_build.hip); binary16 records under the same conditions as on the host
 		n_recs = n_spheres - 1;
-		half = c->allow_half && n_recs <= 65535;
+		half = c->allow_half;
 		for (uint32_t i = 0; half && i < n_spheres; i++) {
 			const float rad = std::sqrt(sph[i].w);
 			const float amax = std::fmax(std::fmax(std::fabs(sph[i].x), std::fabs(sph[i].y)), std::fabs(sph[i].z)) + rad * 1.0001f;
@@ -529,7 +531,8 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
 	s.half_boxes = half ? 1u : 0u;
-	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half);
+	s.stack16 = (half && n_recs <= 65535) ? 1u : 0u;
+	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half, s.stack16 != 0);
 	if (static_cast<uint64_t>(n_recs) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u <= budget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
 	else { s.lds_recs = std::min<uint32_t>(n_recs, budget / rec_bytes); s.lds_spheres = 0; }
 	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
