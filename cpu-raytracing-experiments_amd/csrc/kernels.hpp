@@ -47,6 +47,7 @@ struct SceneDev {
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
+	uint32_t multi_prim_leaves; // 1: some leaf holds more than one prim (only a caller's tree with policy.reference_tree can)
 	uint32_t stack16;           // 1: record indices fit 16 bits and the LDS stack holds u16 entries (binary16 records, <= 65535 of them)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
@@ -330,7 +331,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	if (COUNT) n_nodes += 2;
 	// The sphere of the first leaf child is requested BEFORE the slab tests (its index comes with the record), so the second
 	// LDS round trip of the step overlaps the ~40 VALU instructions of the two box tests instead of following them.
-	const bool leaf_a = (c0 & kLeafBit) != 0u, leaf_b = (c1 & kLeafBit) != 0u;
+	const bool leaf_a = static_cast<int32_t>(c0) < 0, leaf_b = static_cast<int32_t>(c1) < 0;      // kLeafBit is the sign bit
 	const uint32_t cand = leaf_a ? c0 : c1;
 	// (Only when the spheres are staged in LDS: from L2 the speculative packets of leaves whose box is then missed cost more
 	// than the overlap gains.)
@@ -362,18 +363,15 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			const uint32_t first = l0 & 0xffffffu;
 			float4 s = s_pre;
 			const bool fetch = on & (!ALL_LDS || pass == 1 || l0 != cand);   // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
-			if (__ballot(fetch) != 0ull) {
-				const uint32_t idx = fetch ? first : 0u;
-				float4 s2;
-				if (ALL_LDS || idx < sc.lds_spheres) s2 = to_float4(lds.spheres[idx]); else s2 = sc.spheres[idx];
-				s = fetch ? s2 : s_pre;
+			if (fetch) {                                                     // divergent on purpose: the load lands in s for these lanes only (a select would cost 4 + 4 moves)
+				if (ALL_LDS || first < sc.lds_spheres) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];
 			}
 			if (COUNT) n_spheres += on ? 1u : 0u;
 			if (ANYHIT) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
 			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 			// leaves with more than one prim (never produced by the builders here; accepted from callers): remaining prims, rare path
-			const uint32_t extra = on ? ((l0 >> 24) & 0x7fu) : 0u;
-			if (__ballot(extra != 0u) != 0ull) {
+			const uint32_t extra = (sc.multi_prim_leaves && on) ? ((l0 >> 24) & 0x7fu) : 0u;
+			if (sc.multi_prim_leaves && __ballot(extra != 0u) != 0ull) {
 				for (uint32_t k = 1; k <= extra; k++) {
 					const uint32_t p = first + k;
 					if (COUNT) n_spheres++;
@@ -397,8 +395,8 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	if (both) {
 		if (sp < lds_entries) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(far); else lds.stack[sp * lstride + threadIdx.x] = far; }
 		else if (sp < kStack) spill.e[sp - lds_entries] = far;
+		sp += 1u;
 	}
-	sp += both ? 1u : 0u;
 	uint32_t next = near;
 	const bool pop = none & (sp != 0u);
 	if (pop) {

@@ -532,6 +532,8 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
 	s.half_boxes = half ? 1u : 0u;
 	s.stack16 = (half && n_recs <= 65535) ? 1u : 0u;
+	s.multi_prim_leaves = 0;
+	if (c->policy.reference_tree) for (uint32_t i = 0; i < n_nodes; i++) if (nodes[i].prim_count > 1) { s.multi_prim_leaves = 1; break; }
 	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half, s.stack16 != 0);
 	if (static_cast<uint64_t>(n_recs) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u <= budget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
 	else { s.lds_recs = std::min<uint32_t>(n_recs, budget / rec_bytes); s.lds_spheres = 0; }
