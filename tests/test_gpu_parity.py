@@ -323,6 +323,25 @@ def test_awkward_scenes_all_tree_builders_equal_brute_force(mirt, seed, n):
         r.close()
 
 
+@pytest.mark.parametrize("hw", [(19, 37), (1, 5), (64, 128)])
+def test_sky_lookup_with_a_real_equirect_image(mirt, hw):
+    """Sky::operator() (Primitives.hpp:35-46): nearest-texel lookup into an RGBA-f32 equirect image through fast_atan2 /
+    fast_asin, scaled by ambient_color, times throughput.r on all three channels (Q10).  The repo ships no env.hdr, so the
+    image is synthetic; every texel is different, so a wrong row, column or channel shows."""
+    h, w = hw
+    sc = mirt.scene.default9()
+    rng = np.random.default_rng(h * 1000 + w)
+    sc.hdri = rng.uniform(0.0, 4.0, (h, w, 4)).astype(np.float32)
+    sc.ambient = np.array([0.7, 0.5, 0.9], dtype=np.float32)
+    o = ob.Oracle(sc, max_bounces=6, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64); o.Accumulate(10)
+    for use_bvh in (False, True):
+        r = mirt.Renderer(sc, max_bounces=6, use_bvh=use_bvh); r.Resize(96, 64); r.Accumulate(10)
+        assert_same(r.accumulator(), o.accumulator(), f"hdri {h}x{w} use_bvh={use_bvh}")
+        assert r.Render(); assert_same(r.GetFrame(), o.Render(), "resolved frame")
+        r.close()
+    assert o.accumulator().max() > 0.5
+
+
 def test_white_furnace_gpu(mirt):
     r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
     assert np.all(r.accumulator() == 1.0)
