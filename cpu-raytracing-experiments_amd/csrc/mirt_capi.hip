@@ -99,6 +99,7 @@ struct mirt_ctx {
 	uint32_t arena_bounces = 0;
 	uint64_t batch_seq = 0;
 
+	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -384,6 +385,17 @@ int check_ready(mirt_ctx* c) {
 	return MIRT_OK;
 }
 
+// Launches what mirt_accumulate_async has deferred.  Every entry point that observes results or changes what a launch
+// reads (scene, camera, policy, size, tile range) calls this first, so deferral is invisible except in timing.
+int flush_deferred(mirt_ctx* c) {
+	if (!c->deferred) return MIRT_OK;
+	const uint32_t n = c->deferred;
+	c->deferred = 0;
+	HIP_TRY(c, hipSetDevice(c->device));
+	int r = ensure_streams(c); if (r) return r;
+	return launch_batch(c, n);
+}
+
 } // namespace
 
 extern "C" {
@@ -437,6 +449,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
                    const int32_t* lights, uint32_t n_lights, const float ambient_color[3],
                    const float* hdri_rgba, uint32_t hdri_w, uint32_t hdri_h) {
 	if (!c) return MIRT_ERR_ARG;
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	if (n_spheres && (!geometry || !bvh_prims)) return fail(c, MIRT_ERR_ARG, "geometry / bvh_prims is NULL");
 	if (n_nodes && !nodes) return fail(c, MIRT_ERR_ARG, "nodes is NULL");
 	if (!materials || n_materials == 0 || n_materials > MIRT_MAX_MATERIALS) return fail(c, MIRT_ERR_ARG, "need 1..%u materials, got %u", MIRT_MAX_MATERIALS, n_materials);
@@ -556,6 +569,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 int mirt_set_camera(mirt_ctx* c, const float pos[3], const float orient_xyzw[4], float half_width, float half_height, float z, float exposure) {
 	if (!c) return MIRT_ERR_ARG;
 	if (!pos || !orient_xyzw) return fail(c, MIRT_ERR_ARG, "pos / orient is NULL");
+	{ const int fr = flush_deferred(c); if (fr) return fr; }                        // deferred accumulations belong to the camera they were issued under
 	for (int k = 0; k < 3; k++) c->camera.pos[k] = pos[k];
 	for (int k = 0; k < 4; k++) c->camera.orient[k] = orient_xyzw[k];
 	c->camera.half_width = half_width; c->camera.half_height = half_height; c->camera.z = z; c->camera.exposure = exposure;
@@ -567,6 +581,7 @@ int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
 	if (!c || !p) return MIRT_ERR_ARG;
 	if (p->max_bounces < 1 || p->max_bounces > 1024) return fail(c, MIRT_ERR_ARG, "max_bounces %u out of range", p->max_bounces);
 	if (p->buckets < 1 || p->buckets > MIRT_MAX_BUCKETS) return fail(c, MIRT_ERR_ARG, "buckets %u out of range 1..%u", p->buckets, MIRT_MAX_BUCKETS);
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	const bool realloc_acc = p->buckets != c->policy.buckets;
@@ -585,6 +600,7 @@ int mirt_get_policy(const mirt_ctx* c, mirt_policy* p) {
 int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
 	if (!c) return MIRT_ERR_ARG;
 	if (width > 65536 || height > 65536) return fail(c, MIRT_ERR_ARG, "size %ux%u too large", width, height);
+	c->deferred = 0;                                                                   // the accumulator is about to be zeroed (Renderer.hpp:61-62)
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	c->width = width; c->height = height;
@@ -599,6 +615,7 @@ int mirt_set_tile_range(mirt_ctx* c, uint32_t first_tile, uint32_t n_tiles) {
 	if (!c) return MIRT_ERR_ARG;
 	const uint64_t all = static_cast<uint64_t>(c->h_tiles) * c->v_tiles;
 	if (static_cast<uint64_t>(first_tile) + n_tiles > all) return fail(c, MIRT_ERR_ARG, "tile range [%u,+%u) exceeds %llu tiles", first_tile, n_tiles, (unsigned long long)all);
+	c->deferred = 0;                                                                   // zeroes the accumulator
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	c->first_tile = first_tile; c->n_tiles = n_tiles;
@@ -607,6 +624,7 @@ int mirt_set_tile_range(mirt_ctx* c, uint32_t first_tile, uint32_t n_tiles) {
 
 int mirt_reset(mirt_ctx* c) {
 	if (!c) return MIRT_ERR_ARG;
+	c->deferred = 0;                                                                   // what was not launched yet would be wiped anyway
 	HIP_TRY(c, hipSetDevice(c->device));
 	return alloc_accumulator(c);                                                      // Renderer.hpp:64-67
 }
@@ -615,16 +633,21 @@ int mirt_accumulate_async(mirt_ctx* c, uint32_t n_calls) {
 	int r = check_ready(c); if (r) return r;
 	HIP_TRY(c, hipSetDevice(c->device));
 	if ((r = ensure_streams(c))) return r;
+	// Whole batches are launched now; a remainder waits for more calls (a frame loop that calls this once per frame still gets
+	// full-size launches) and is launched by the next call that needs it: mirt_synchronize, a read, a state change.
 	const uint32_t limit = batch_limit(c);
-	while (n_calls) {
-		const uint32_t bn = std::min(n_calls, limit);
-		if ((r = launch_batch(c, bn))) return r;
-		n_calls -= bn;
+	uint64_t total = static_cast<uint64_t>(c->deferred) + n_calls;
+	c->deferred = 0;
+	while (total >= limit) {
+		if ((r = launch_batch(c, limit))) return r;
+		total -= limit;
 	}
+	c->deferred = static_cast<uint32_t>(total);
 	return MIRT_OK;
 }
 int mirt_synchronize(mirt_ctx* c) {
 	if (!c) return MIRT_ERR_ARG;
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	return MIRT_OK;
@@ -634,7 +657,7 @@ int mirt_accumulate(mirt_ctx* c, uint32_t n_calls) {
 	if (r) return r;
 	return mirt_synchronize(c);
 }
-int mirt_get_accumulations(const mirt_ctx* c, uint32_t* a) { if (!c || !a) return MIRT_ERR_ARG; *a = c->accumulations; return MIRT_OK; }
+int mirt_get_accumulations(const mirt_ctx* c, uint32_t* a) { if (!c || !a) return MIRT_ERR_ARG; *a = c->accumulations + c->deferred; return MIRT_OK; }
 
 int mirt_accumulator_floats(const mirt_ctx* c, size_t* n) {
 	if (!c || !n) return MIRT_ERR_ARG;
@@ -644,6 +667,7 @@ int mirt_accumulator_floats(const mirt_ctx* c, size_t* n) {
 int mirt_read_accumulator(mirt_ctx* c, float* dst) {
 	if (!c || !dst) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	if (n) HIP_TRY(c, hipMemcpy(dst, c->accumulator.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -652,12 +676,14 @@ int mirt_read_accumulator(mirt_ctx* c, float* dst) {
 int mirt_accumulator_device(mirt_ctx* c, void** ptr, size_t* bytes) {
 	if (!c || !ptr || !bytes) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	*ptr = c->accumulator.ptr; *bytes = n * sizeof(float);
 	return MIRT_OK;
 }
 int mirt_load_accumulator(mirt_ctx* c, const float* src, int src_is_device, uint32_t accumulations) {
 	if (!c || !src) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
+	c->deferred = 0;                                                                   // overwritten below
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	if (n) HIP_TRY(c, hipMemcpy(c->accumulator.ptr, src, n * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -669,7 +695,9 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 	int r = check_ready(c); if (r) return r;
 	if (!rgba_host) return fail(c, MIRT_ERR_ARG, "rgba_host is NULL");
 	const uint32_t k = c->policy.buckets;
-	if (c->accumulations == 0 || (c->accumulations % k) != 0) return MIRT_NOT_READY;               // Renderer.hpp:437
+	const uint32_t issued = c->accumulations + c->deferred;
+	if (issued == 0 || (issued % k) != 0) return MIRT_NOT_READY;                                    // Renderer.hpp:437 (nothing is launched for this)
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	const float scale = c->camera.exposure / static_cast<float>(c->accumulations / k);              // Renderer.hpp:439
 	const uint32_t n_pix = c->n_tiles * kTileSize;
@@ -693,6 +721,7 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 
 int mirt_get_counters(mirt_ctx* c, mirt_counters* out) {
 	if (!c || !out) return MIRT_ERR_ARG;
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	DevCounters d;

@@ -153,7 +153,10 @@ public:
 		check(mirt_resize(ctx_, width, height), "mirt_resize");
 	}
 	void ResetAccumulator() { check(mirt_reset(ctx_), "mirt_reset"); }    // Renderer.hpp:64-67
-	void Accumulate(uint32_t n_calls = 1) { check(mirt_accumulate(ctx_, n_calls), "mirt_accumulate"); }   // Renderer.hpp:73-434
+	// Renderer.hpp:73-434.  Asynchronous: Render() / counters() / the destructor wait for the GPU; called once per frame the library
+	// still batches the frames between two Render()s that are due (mirt.h, mirt_accumulate_async).
+	void Accumulate(uint32_t n_calls = 1) { check(mirt_accumulate_async(ctx_, n_calls), "mirt_accumulate_async"); }
+	void Synchronize() { check(mirt_synchronize(ctx_), "mirt_synchronize"); }
 	bool Render() {                                                        // Renderer.hpp:436-478; false = frame unchanged (:437)
 		const int rc = mirt_render(ctx_, framebuffer.data());
 		check(rc, "mirt_render");

@@ -1,0 +1,32 @@
+"""The reference's frame loop (Application.cpp:379-380): Accumulate(); Render(); once per frame, versus handing the library n frames at once."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+mirt = importlib.import_module("cpu-raytracing-experiments_amd")
+sc = mirt.scene.synthetic(1000, ambient=0.5)
+r = mirt.Renderer(sc, max_bounces=5, use_bvh=True); r.Resize(1024, 1024)
+r.Accumulate(10)
+for label, fn, n in (("Accumulate(); Render() per frame", lambda: (r.Accumulate(1), r.Render()), 100),
+                     ("Accumulate() per frame, Render() every 5th", None, 100),
+                     ("AccumulateAsync(1); Render() per frame (the host mirror)", None, 100),
+                     ("AccumulateAsync(1) x 100, one Synchronize", None, 100),
+                     ("Accumulate(100)", None, 100)):
+    c0 = r.counters()["rays"]; t0 = time.perf_counter()
+    if label.startswith("Accumulate(); Render()"):
+        for _ in range(n): fn()
+    elif label.startswith("Accumulate() per frame"):
+        for i in range(n):
+            r.Accumulate(1)
+            if r.accumulations % 5 == 0: r.Render()
+    elif label.startswith("AccumulateAsync(1); Render"):
+        for _ in range(n):
+            r.AccumulateAsync(1); r.Render()
+        r.Synchronize()
+    elif label.startswith("AccumulateAsync"):
+        for _ in range(n): r.AccumulateAsync(1)
+        r.Synchronize()
+    else:
+        r.Accumulate(n)
+    dt = time.perf_counter() - t0
+    print(f"{label:58s}: {dt / n * 1e3:6.2f} ms per frame, {(r.counters()['rays'] - c0) / dt / 1e6:7.0f} Mray/s", flush=True)
+r.close()

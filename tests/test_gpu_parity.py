@@ -342,6 +342,37 @@ def test_sky_lookup_with_a_real_equirect_image(mirt, hw):
     assert o.accumulator().max() > 0.5
 
 
+def test_frame_loop_with_deferred_batches(mirt):
+    """The reference's UI loop calls Accumulate(); Render(); once per frame (Application.cpp:379-380) and moves the camera in
+    between.  mirt_accumulate_async defers partial batches: frames between two due Render()s are traced together, deferred
+    frames keep the camera they were issued under, and every observer sees all issued frames."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True); r.Resize(96, 64)
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64)
+    frames_shown = 0
+    for frame in range(1, 24):
+        if frame == 8:                                       # camera move: the app resets (Application.cpp:332)
+            sc.camera.pos = sc.camera.pos + np.array([0.5, 0.0, 0.0], dtype=np.float32)
+            for x in (r, o):
+                x.UpdateCamera() if x is r else x.update_camera()
+                x.ResetAccumulator()
+        if frame == 15:                                      # camera change WITHOUT reset: frames issued before keep the old camera
+            sc.camera.pos = sc.camera.pos + np.array([0.0, 0.25, 0.0], dtype=np.float32)
+            r.UpdateCamera(); o.update_camera()
+        r.AccumulateAsync(1); o.Accumulate(1)
+        assert r.accumulations == o.accumulations            # issued frames are counted at once
+        shown = r.Render()
+        want = o.Render()
+        assert shown == (want is not None)
+        if shown:
+            frames_shown += 1
+            assert_same(r.GetFrame(), want, f"frame {frame}")
+    assert frames_shown >= 3
+    assert_same(r.accumulator(), o.accumulator(), "accumulator after the loop")
+    assert r.counters()["rays"] == o.counters()["rays"]
+    r.close()
+
+
 def test_white_furnace_gpu(mirt):
     r = mirt.Renderer(mirt.scene.white_furnace(), use_bvh=True); r.Resize(64, 64); r.Accumulate(5)
     assert np.all(r.accumulator() == 1.0)
