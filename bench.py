@@ -128,14 +128,16 @@ def main():
     scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
     width, height = shape_for(world, cfg["width"])
     tiles = (width // 16) * (height // 16)
-    first, count = mirt.distributed.tile_range(tiles, rank, world)
+    h_tiles, v_tiles = width // 16, height // 16
+    first_row, row_stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)     # interleaved tile rows: every rank sees sky and ground alike
+    count = n_rows * h_tiles
 
     r = mirt.Renderer(scene_fn(), device=local_rank, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True,
                       use_bvh=bool(cfg["use_bvh"]), profile=True, streams=args.streams, max_batch=args.max_batch)
     n_streams = args.streams or 3
     r.Resize(width, height)
     if world > 1:
-        r.SetTileRange(first, count)
+        r.SetTileRows(first_row, row_stride)
     spp, K, W = cfg["spp"], args.steps, args.warmup
 
     def sync_all():
@@ -169,7 +171,7 @@ def main():
             local = local.cpu()
         sync_all()
         g0 = time.perf_counter()
-        full = mirt.distributed.gather_accumulator(local, tiles, rank, world, cfg["buckets"])
+        full = mirt.distributed.gather_accumulator_rows(local, h_tiles, v_tiles, rank, world, cfg["buckets"])
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
@@ -270,7 +272,7 @@ def main():
             "config": {"workload": "cfg2: S(1000) spheres + SAH BVH, MIS, Policy.max_bounces=5 (primary+4 bounces), "
                                    f"{spp} accumulations/step, 1024x1024 px per GPU", "image": f"{width}x{height}",
                        "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
-                       "parallelism": f"tile-sharded x{world}" if world > 1 else "single GPU", "batches_in_flight": n_streams,
+                       "parallelism": f"tile rows interleaved over {world} GPUs, one RCCL gather" if world > 1 else "single GPU", "batches_in_flight": n_streams,
                        "accumulations_per_batch": min(r.get_policy()["max_batch"], spp)},
             "rays_per_step": rays_total / K,
             "shadow_rays_per_step": (counts["shadow_rays"] / K) if counts else None,

@@ -80,7 +80,7 @@ def load_library():
         "mirt_set_policy": [P, C.POINTER(Policy)],
         "mirt_get_policy": [P, C.POINTER(Policy)],
         "mirt_resize": [P, u32, u32],
-        "mirt_set_tile_range": [P, u32, u32],
+        "mirt_set_tile_range": [P, u32, u32], "mirt_set_tile_rows": [P, u32, u32],
         "mirt_reset": [P],
         "mirt_accumulate": [P, u32],
         "mirt_accumulate_async": [P, u32],
@@ -253,6 +253,10 @@ class Renderer:
     # -- sharding / state access -------------------------------------------------------------------
     def SetTileRange(self, first_tile: int, n_tiles: int):
         self._check(self._lib.mirt_set_tile_range(self._ctx, first_tile, n_tiles))
+
+    def SetTileRows(self, first_row: int, row_stride: int):
+        """Multi-GPU sharding by interleaved tile rows: this context renders tile rows first_row, first_row + row_stride, ..."""
+        self._check(self._lib.mirt_set_tile_rows(self._ctx, first_row, row_stride))
 
     @property
     def accumulations(self) -> int:

@@ -76,6 +76,8 @@ struct FrameParams {
 	CameraParams cam;
 	uint32_t h_tiles;           // Renderer.hpp:59
 	uint32_t first_tile;        // first global LaunchIndex owned by this context
+	uint32_t run_tiles;         // the context owns runs of run_tiles consecutive LaunchIndices, stride_tiles apart (interleaved tile rows,
+	uint32_t stride_tiles;      // mirt_set_tile_rows); stride_tiles = 0: one contiguous range (mirt_set_tile_range)
 	uint32_t n_pix;             // local pixels = local tiles * 256
 	uint32_t acc_base;          // `accumulations` before this batch
 	uint32_t batch_n;           // accumulations in flight in this batch
@@ -535,8 +537,15 @@ MIRT_DI bool bvh_all_in_lds(const SceneDev& sc) { return sc.lds_recs == sc.n_rec
 // RAY GENERATION — Renderer.hpp:97-127 (stream init is implicit: radiance 0 / throughput 1 are
 // supplied by k_shade<FIRST>, so only p, dir and the path id are written)
 // ------------------------------------------------------------------------------------------------
+// Global LaunchIndex (Renderer.hpp:75,84-88) of this context's local tile.
+MIRT_DI uint32_t global_tile(uint32_t first_tile, uint32_t run_tiles, uint32_t stride_tiles, uint32_t local_tile) {
+	if (stride_tiles == 0u) return first_tile + local_tile;             // wave-uniform branch
+	const uint32_t run = local_tile / run_tiles;
+	return first_tile + run * stride_tiles + (local_tile - run * run_tiles);
+}
+MIRT_DI uint32_t global_tile(const FrameParams& fp, uint32_t local_tile) { return global_tile(fp.first_tile, fp.run_tiles, fp.stride_tiles, local_tile); }
 MIRT_DI uint32_t path_seed(const FrameParams& fp, uint32_t pix) {      // seed[ID], Renderer.hpp:107 (wraps like the int32 cast)
-	return (fp.first_tile * kTileSize + pix) * (fp.max_bounces * 2u + 1u);
+	return (global_tile(fp, pix >> 8) * kTileSize + (pix & 255u)) * (fp.max_bounces * 2u + 1u);
 }
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out, uint32_t* stream_count) {
 	const uint32_t total = fp.n_pix * fp.batch_n;
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
 		const uint32_t slot = i / fp.n_pix;
 		const uint32_t pix = i - slot * fp.n_pix;
-		const uint32_t tile = fp.first_tile + (pix >> 8);
+		const uint32_t tile = global_tile(fp, pix >> 8);
 		const uint32_t ID = pix & 255u;
 		const int32_t x = static_cast<int32_t>(kTileRoot * (tile % fp.h_tiles) + (ID & 15u));
 		const int32_t y = static_cast<int32_t>(kTileRoot * (tile / fp.h_tiles) + (ID >> 4));
@@ -982,7 +991,7 @@ MIRT_DI float median_k(float* v, uint32_t k) {
 	return (k & 1u) ? v[k / 2] : (v[k / 2 - 1] + v[k / 2]) * 0.5f;
 }
 __global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ accum, float4* __restrict__ fb, uint32_t n_pix, uint32_t first_tile,
-                                                    uint32_t h_tiles, uint32_t width, uint32_t buckets, float scale) {
+                                                    uint32_t run_tiles, uint32_t stride_tiles, uint32_t h_tiles, uint32_t width, uint32_t buckets, float scale) {
 	for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < n_pix; pix += gridDim.x * kBlock) {
 		const float* src = accum + static_cast<size_t>(pix >> 8) * buckets * 3u * kTileSize + (pix & 255u);
 		float ch[3];
@@ -992,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ ac
 			ch[c] = scale * median_k(v, buckets);                               // Renderer.hpp:453-455
 		}
 		tonemapping(ch[0], ch[1], ch[2]);                                       // Renderer.hpp:461
-		const uint32_t tile = first_tile + (pix >> 8), ID = pix & 255u;
+		const uint32_t tile = global_tile(first_tile, run_tiles, stride_tiles, pix >> 8), ID = pix & 255u;
 		const uint32_t x = kTileRoot * (tile % h_tiles) + (ID & 15u);
 		const uint32_t y = kTileRoot * (tile / h_tiles) + (ID >> 4);
 		fb[static_cast<size_t>(y) * width + x] = make_float4(ch[0], ch[1], ch[2], 1.0f);   // Renderer.hpp:447,465

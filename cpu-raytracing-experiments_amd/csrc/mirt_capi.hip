@@ -79,6 +79,7 @@ struct mirt_ctx {
 	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, 0, { 0, 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t first_tile = 0, n_tiles = 0;
+	uint32_t run_tiles = 0, stride_tiles = 0;   // interleaved tile rows (mirt_set_tile_rows); stride 0 = one contiguous range
 	uint32_t accumulations = 0;
 	bool have_scene = false, have_camera = false;
 
@@ -275,6 +276,8 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	fp.cam = c->camera;
 	fp.h_tiles = c->h_tiles;
 	fp.first_tile = c->first_tile;
+	fp.run_tiles = c->run_tiles ? c->run_tiles : 1u;
+	fp.stride_tiles = c->stride_tiles;
 	fp.n_pix = c->n_tiles * kTileSize;
 	fp.acc_base = acc_base;
 	fp.batch_n = batch_n;
@@ -605,7 +608,7 @@ int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
 	HIP_TRY(c, sync_all(c));
 	c->width = width; c->height = height;
 	c->h_tiles = width / MIRT_TILE_ROOT; c->v_tiles = height / MIRT_TILE_ROOT;          // Renderer.hpp:59-60
-	c->first_tile = 0; c->n_tiles = c->h_tiles * c->v_tiles;
+	c->first_tile = 0; c->n_tiles = c->h_tiles * c->v_tiles; c->run_tiles = 0; c->stride_tiles = 0;
 	HIP_TRY(c, c->framebuffer.ensure(std::max<size_t>(static_cast<size_t>(width) * height, 1) * sizeof(float4)));
 	HIP_TRY(c, hipMemsetAsync(c->framebuffer.ptr, 0, c->framebuffer.bytes, c->stream));
 	return alloc_accumulator(c);                                                      // Renderer.hpp:61-62
@@ -618,7 +621,19 @@ int mirt_set_tile_range(mirt_ctx* c, uint32_t first_tile, uint32_t n_tiles) {
 	c->deferred = 0;                                                                   // zeroes the accumulator
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
-	c->first_tile = first_tile; c->n_tiles = n_tiles;
+	c->first_tile = first_tile; c->n_tiles = n_tiles; c->run_tiles = 0; c->stride_tiles = 0;
+	return alloc_accumulator(c);
+}
+
+int mirt_set_tile_rows(mirt_ctx* c, uint32_t first_row, uint32_t row_stride) {
+	if (!c) return MIRT_ERR_ARG;
+	if (row_stride == 0) return fail(c, MIRT_ERR_ARG, "row_stride must be at least 1");
+	c->deferred = 0;                                                                   // zeroes the accumulator
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, sync_all(c));
+	const uint32_t rows = first_row < c->v_tiles ? (c->v_tiles - first_row + row_stride - 1) / row_stride : 0u;
+	c->first_tile = first_row * c->h_tiles; c->n_tiles = rows * c->h_tiles;
+	c->run_tiles = c->h_tiles; c->stride_tiles = row_stride > 1 ? row_stride * c->h_tiles : 0u;
 	return alloc_accumulator(c);
 }
 
@@ -704,12 +719,13 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 	HIP_TRY(c, sync_all(c));
 	{ Bracket t(c, MIRT_K_RESOLVE);
 	  hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n_pix)), dim3(kBlock), 0, c->stream, c->accumulator.as<float>(), c->framebuffer.as<float4>(),
-	                     n_pix, c->first_tile, c->h_tiles, c->width, k, scale); }
+	                     n_pix, c->first_tile, c->run_tiles ? c->run_tiles : 1u, c->stride_tiles, c->h_tiles, c->width, k, scale); }
 	HIP_TRY(c, hipGetLastError());
 	std::vector<float> staging(static_cast<size_t>(c->width) * c->height * 4);
 	HIP_TRY(c, hipMemcpyAsync(staging.data(), c->framebuffer.ptr, staging.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	for (uint32_t t = c->first_tile; t < c->first_tile + c->n_tiles; t++) {                         // only this context's tiles
+	for (uint32_t local = 0; local < c->n_tiles; local++) {                                         // only this context's tiles
+		const uint32_t t = c->stride_tiles ? c->first_tile + (local / c->run_tiles) * c->stride_tiles + local % c->run_tiles : c->first_tile + local;
 		const uint32_t x0 = MIRT_TILE_ROOT * (t % c->h_tiles), y0 = MIRT_TILE_ROOT * (t / c->h_tiles);
 		for (uint32_t row = 0; row < MIRT_TILE_ROOT; row++) {
 			const size_t off = (static_cast<size_t>(y0 + row) * c->width + x0) * 4;

@@ -148,6 +148,11 @@ int mirt_resize(mirt_ctx* ctx, uint32_t width, uint32_t height);
  * [first_tile, first_tile + n_tiles).  RNG seeds use the global LaunchIndex (Renderer.hpp:107), so any
  * partition reproduces the single-context result bit for bit.  Reallocates and zeroes the accumulator. */
 int mirt_set_tile_range(mirt_ctx* ctx, uint32_t first_tile, uint32_t n_tiles);
+/* The same with interleaved tile rows: this context renders the tile rows first_row, first_row + row_stride, ... (a tile row =
+ * width/16 consecutive LaunchIndices).  With rank r of N taking (r, N) every GPU sees the whole image height, sky and ground
+ * alike: contiguous eighths of the weak-scaling image differ by 1.5x in cost (profiles/experiments/shard_balance.py).  The
+ * accumulator slab holds the owned rows in ascending order.  Reallocates and zeroes the accumulator. */
+int mirt_set_tile_rows(mirt_ctx* ctx, uint32_t first_row, uint32_t row_stride);
 /* Renderer::ResetAccumulator, Renderer.hpp:64-67 */
 int mirt_reset(mirt_ctx* ctx);
 

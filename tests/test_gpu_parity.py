@@ -407,6 +407,34 @@ def test_sharded_contexts_reproduce_the_whole(mirt):
     assert_same(np.concatenate(parts), want, "sharded vs whole")
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_interleaved_tile_rows_reproduce_the_whole(mirt, world):
+    """mirt_set_tile_rows: rank r renders tile rows r, r+N, ... (what bench.py --gpus N uses: every GPU gets sky and ground
+    alike).  Slabs put back row by row give the single-context accumulator bit for bit, and each context's Render() fills
+    exactly its own rows of the frame."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    w, h, spp = 208, 192, 10                                 # 13 x 12 tiles: 12 rows do not divide by 5
+    h_tiles, v_tiles = w // 16, h // 16
+    whole = mirt.Renderer(sc, max_bounces=5, use_bvh=True); whole.Resize(w, h); whole.Accumulate(spp)
+    want = whole.accumulator().reshape(v_tiles, h_tiles, -1); assert whole.Render(); want_frame = whole.GetFrame().copy(); whole.close()
+    got = np.zeros_like(want); frame = np.zeros_like(want_frame)
+    for rank in range(world):
+        first_row, stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True); r.Resize(w, h); r.SetTileRows(first_row, stride); r.Accumulate(spp)
+        acc = r.accumulator()
+        assert acc.size == n_rows * h_tiles * 5 * 3 * 256
+        got[rank::world] = acc.reshape(n_rows, h_tiles, -1)
+        assert r.Render()
+        mine = r.GetFrame()
+        rows = np.concatenate([np.arange(16 * tr, 16 * tr + 16) for tr in range(rank, v_tiles, world)])
+        other = np.setdiff1d(np.arange(h), rows)
+        assert not mine[other].any()                         # rows of other ranks stay untouched
+        frame[rows] = mine[rows]
+        r.close()
+    assert_same(got, want, f"interleaved rows over {world} contexts vs whole")
+    assert_same(frame, want_frame, "frames assembled from the ranks' rows")
+
+
 def test_batching_and_call_splitting_do_not_change_results(mirt):
     sc = mirt.scene.default9()
     a = mirt.Renderer(sc, use_bvh=True); a.Resize(128, 64); a.Accumulate(13)

@@ -31,6 +31,15 @@ def _worker(rank, world, port, out_path):
         if rank == 0:
             np.save(out_path, gathered.numpy())
             assert np.array_equal(gathered.numpy().view(np.uint32), full.view(np.uint32))
+        # interleaved tile rows (what bench.py uses): rank r keeps rows r, r+N, ...; the root un-interleaves after the gather
+        h_tiles, v_tiles = w // 16, h // 16
+        first_row, stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)
+        rows = full.reshape(v_tiles, h_tiles, 5, 3, 256)[first_row::stride]
+        assert rows.shape[0] == n_rows
+        local = torch.from_numpy(rows.reshape(n_rows * h_tiles, 5, 3, 256).copy())
+        gathered = mirt.distributed.gather_accumulator_rows(local, h_tiles, v_tiles, rank, world, buckets=5)
+        if rank == 0:
+            assert np.array_equal(gathered.numpy().view(np.uint32), full.view(np.uint32))
     finally:
         dist.destroy_process_group()
 
@@ -44,6 +53,18 @@ def test_tile_ranges_cover_everything():
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_tile_rows_cover_everything():
+    mirt = load_mirt()
+    for v_tiles in (1, 3, 12, 64, 128):
+        for world in (1, 2, 3, 8):
+            owned = []
+            for r in range(world):
+                first, stride, n = mirt.distributed.tile_rows(v_tiles, r, world)
+                owned += list(range(first, v_tiles, stride))
+                assert n == len(range(first, v_tiles, stride))
+            assert sorted(owned) == list(range(v_tiles))
 
 
 @pytest.mark.timeout(300)
