@@ -178,6 +178,9 @@ void mirt_host::build_sah_tree(const mirt_sphere* prims, uint32_t n, std::vector
 
 extern "C" int mirt_bvh_build(const mirt_sphere* geometry, uint32_t n, mirt_bvh_node* nodes_out, uint32_t* n_nodes_out, mirt_sphere* prims_out) {
 	if ((!geometry && n) || !nodes_out || !n_nodes_out || (!prims_out && n)) return MIRT_ERR_ARG;
+	for (uint32_t i = 0; i < n; i++)                                                     // NaNs would break the centroid sorts' ordering
+		if (!std::isfinite(geometry[i].position[0]) || !std::isfinite(geometry[i].position[1]) || !std::isfinite(geometry[i].position[2]) ||
+		    !std::isfinite(geometry[i].radius_sq) || geometry[i].radius_sq < 0.0f) return MIRT_ERR_ARG;
 	std::vector<mirt_bvh_node> nodes;
 	SweepBuilder builder(geometry, n);
 	builder.run(nodes, prims_out);

@@ -463,6 +463,10 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 		if (geometry[i].material_ID < 0 || static_cast<uint32_t>(geometry[i].material_ID) >= n_materials ||
 		    bvh_prims[i].material_ID < 0 || static_cast<uint32_t>(bvh_prims[i].material_ID) >= n_materials)
 			return fail(c, MIRT_ERR_ARG, "sphere %u: material_ID out of range", i);
+		// non-finite centres or radii would reach the tree builders' sorts and the box arithmetic as NaN (the reference has no check; UB there)
+		for (const mirt_sphere* s : { &geometry[i], &bvh_prims[i] })
+			if (!std::isfinite(s->position[0]) || !std::isfinite(s->position[1]) || !std::isfinite(s->position[2]) || !std::isfinite(s->radius_sq) || s->radius_sq < 0.0f)
+				return fail(c, MIRT_ERR_ARG, "sphere %u: position / radius_sq must be finite, radius_sq >= 0", i);
 	}
 	for (uint32_t i = 0; i < n_lights; i++)
 		if (lights[i] < 0 || static_cast<uint32_t>(lights[i]) >= n_spheres) return fail(c, MIRT_ERR_ARG, "light %u: index out of range", i);

@@ -520,6 +520,12 @@ def test_edge_cases_and_errors(mirt):
     bad = mirt.scene.default9(); bad.geometry["material_ID"][3] = 99
     with pytest.raises(mirt.MirtError):
         mirt.Renderer(bad)
+    for field, value in (("position", np.nan), ("position", np.inf), ("radius_sq", -1.0), ("radius_sq", np.nan)):
+        bad = mirt.scene.default9()
+        if field == "position": bad.geometry["position"][2, 1] = value
+        else: bad.geometry["radius_sq"][2] = value
+        with pytest.raises(mirt.MirtError):                  # non-finite geometry is refused (host builder and mirt_set_scene), not traced
+            mirt.Renderer(bad)
 
 
 def test_cpp_host_matches_python_host(mirt, tmp_path):
