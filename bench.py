@@ -65,15 +65,16 @@ def cpu_baseline(mirt, scene_fn, cfg, log):
     rays = o.counters()["rays"]
     log(f"cpu baseline: {n} accumulations, {rays} rays in {dt:.2f}s on {threads} threads")
     out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-           "sample": f"{n} of {cfg['spp']} accumulations of the same {cfg['width']}x{cfg['height']} S(1000) workload, "
+           "sample": f"{n} of {cfg['spp']} accumulations of the same {cfg['width']}x{cfg['height']} S({cfg['n']}) workload, "
                      f"oracle stream-BVH mode (reference BVH.hpp:320-358 restated; reference itself unbuildable here)"}
     # the reference AS SHIPPED traverses nothing (#define USEBVH false, BVH.hpp:307): brute force over all spheres (SURVEY.md §8d asks for both)
     try:
         b = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_BRUTE, threads=threads)
-        b.Resize(256, 256)
+        win = 256 if cfg["n"] <= 2000 else 128 if cfg["n"] <= 20000 else 48          # cost grows with the sphere count: keep the sample to seconds
+        b.Resize(win, win)
         t0 = time.perf_counter(); b.Accumulate(2); dtb = time.perf_counter() - t0
         out["as_shipped_brute_force"] = {"value": b.counters()["rays"] / dtb / 1e6, "unit": "Mray/s", "cores": threads,
-                                         "sample": "2 accumulations of a 256x256 window of the same scene and camera (USEBVH false: every ray tests all 1000 spheres)"}
+                                         "sample": f"2 accumulations of a {win}x{win} window of the same scene and camera (USEBVH false: every ray tests all {cfg['n']} spheres)"}
         b.close()
     except Exception as e:                                   # the headline baseline above is what the contract needs
         log(f"brute-force cpu baseline skipped: {e}")
@@ -89,6 +90,9 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="accumulations per step (default: cfg2's 64)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
     ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 32 M primary rays)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE config. cfg2 (default, the metric's config) scales weakly: 1024x1024 px per GPU. The others keep their own image "
+                         "(cfg3 1920x1088, cfg4/5 4096x4096) and split its tile rows over the ranks (strong scaling); --spp bounds the accumulations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the counting replay (roofline.achieved becomes null)")
     args = ap.parse_args()
@@ -122,11 +126,14 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    cfg = dict(mirt.scene.CONFIGS["cfg2"])
+    cfg = dict(mirt.scene.CONFIGS[args.config])
+    weak = args.config == "cfg2"
     if args.spp:
         cfg["spp"] = args.spp
+    elif not weak:
+        cfg["spp"] = 64                                      # one step = 64 accumulations whatever the config's total
     scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
-    width, height = shape_for(world, cfg["width"])
+    width, height = shape_for(world, cfg["width"]) if weak else (cfg["width"], cfg["height"])
     tiles = (width // 16) * (height // 16)
     h_tiles, v_tiles = width // 16, height // 16
     first_row, row_stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)     # interleaved tile rows: every rank sees sky and ground alike
@@ -267,10 +274,11 @@ def main():
                     pass
         out = {
             "metric": "Mray/s (primary+bounce)", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: S(1000) spheres + SAH BVH, MIS, Policy.max_bounces=5 (primary+4 bounces), "
-                                   f"{spp} accumulations/step, 1024x1024 px per GPU", "image": f"{width}x{height}",
+            "config": {"workload": (f"{args.config}: S({cfg['n']}) spheres + SAH BVH, MIS, Policy.max_bounces={cfg['max_bounces']} "
+                                    f"(primary+{cfg['max_bounces'] - 1} bounces), {spp} accumulations/step, "
+                                    + ("1024x1024 px per GPU" if weak else f"{width}x{height} px over all GPUs")), "image": f"{width}x{height}",
                        "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
                        "parallelism": f"tile rows interleaved over {world} GPUs, one RCCL gather" if world > 1 else "single GPU", "batches_in_flight": n_streams,
                        "accumulations_per_batch": min(r.get_policy()["max_batch"], spp)},
