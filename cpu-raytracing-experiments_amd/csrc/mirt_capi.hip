@@ -94,6 +94,8 @@ struct mirt_ctx {
 	// frame state
 	DeviceBuffer accumulator;        // [local tile][bucket][3][256] f32
 	DeviceBuffer framebuffer;        // width*height float4
+	float* frame_host = nullptr;     // pinned staging copy of the framebuffer for mirt_render (pageable memory halves the copy rate)
+	size_t frame_host_bytes = 0;
 	DeviceBuffer counters;           // DevCounters
 	std::vector<PipeSlot> slots;     // batches in flight (policy.streams)
 	uint32_t capacity = 0;           // rays per stream plane
@@ -442,6 +444,7 @@ int mirt_destroy(mirt_ctx* c) {
 	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->light_sphere, &c->light_emit, &c->mat_albedo, &c->mat_emission,
 	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->counters };
 	for (DeviceBuffer* b : bufs) b->release();
+	if (c->frame_host) (void)hipHostFree(c->frame_host);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MIRT_OK;
@@ -615,6 +618,12 @@ int mirt_resize(mirt_ctx* c, uint32_t width, uint32_t height) {
 	c->first_tile = 0; c->n_tiles = c->h_tiles * c->v_tiles; c->run_tiles = 0; c->stride_tiles = 0;
 	HIP_TRY(c, c->framebuffer.ensure(std::max<size_t>(static_cast<size_t>(width) * height, 1) * sizeof(float4)));
 	HIP_TRY(c, hipMemsetAsync(c->framebuffer.ptr, 0, c->framebuffer.bytes, c->stream));
+	if (c->frame_host_bytes < c->framebuffer.bytes) {
+		if (c->frame_host) (void)hipHostFree(c->frame_host);
+		c->frame_host = nullptr; c->frame_host_bytes = 0;
+		HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->frame_host), c->framebuffer.bytes, hipHostMallocDefault));
+		c->frame_host_bytes = c->framebuffer.bytes;
+	}
 	return alloc_accumulator(c);                                                      // Renderer.hpp:61-62
 }
 
@@ -725,15 +734,17 @@ int mirt_render(mirt_ctx* c, float* rgba_host) {
 	  hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n_pix)), dim3(kBlock), 0, c->stream, c->accumulator.as<float>(), c->framebuffer.as<float4>(),
 	                     n_pix, c->first_tile, c->run_tiles ? c->run_tiles : 1u, c->stride_tiles, c->h_tiles, c->width, k, scale); }
 	HIP_TRY(c, hipGetLastError());
-	std::vector<float> staging(static_cast<size_t>(c->width) * c->height * 4);
-	HIP_TRY(c, hipMemcpyAsync(staging.data(), c->framebuffer.ptr, staging.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	const size_t frame_floats = static_cast<size_t>(c->width) * c->height * 4;
+	const bool whole = c->n_tiles == c->h_tiles * c->v_tiles && c->width == c->h_tiles * MIRT_TILE_ROOT && c->height == c->v_tiles * MIRT_TILE_ROOT;
+	HIP_TRY(c, hipMemcpyAsync(c->frame_host, c->framebuffer.ptr, frame_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	for (uint32_t local = 0; local < c->n_tiles; local++) {                                         // only this context's tiles
+	if (whole) std::memcpy(rgba_host, c->frame_host, frame_floats * sizeof(float));   // every pixel is this context's
+	else for (uint32_t local = 0; local < c->n_tiles; local++) {                                    // only this context's tiles
 		const uint32_t t = c->stride_tiles ? c->first_tile + (local / c->run_tiles) * c->stride_tiles + local % c->run_tiles : c->first_tile + local;
 		const uint32_t x0 = MIRT_TILE_ROOT * (t % c->h_tiles), y0 = MIRT_TILE_ROOT * (t / c->h_tiles);
 		for (uint32_t row = 0; row < MIRT_TILE_ROOT; row++) {
 			const size_t off = (static_cast<size_t>(y0 + row) * c->width + x0) * 4;
-			std::memcpy(rgba_host + off, staging.data() + off, MIRT_TILE_ROOT * 4 * sizeof(float));
+			std::memcpy(rgba_host + off, c->frame_host + off, MIRT_TILE_ROOT * 4 * sizeof(float));
 		}
 	}
 	return MIRT_OK;

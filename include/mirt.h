@@ -162,7 +162,7 @@ int mirt_accumulate(mirt_ctx* ctx, uint32_t n_calls);
  * remainder is kept until later calls complete the batch or something needs it — mirt_synchronize, mirt_render when a frame
  * is due, any read of results, any change of scene / camera / policy (the deferred calls are launched with the state they
  * were issued under).  A host that calls this once per frame, as the reference's UI loop calls Accumulate() (Application.cpp:379),
- * therefore still gets full-size launches: 2.2 ms -> 0.9 ms per 1024x1024 frame with Render() called every frame (due every 5th). */
+ * therefore still gets full-size launches: 2.1 ms -> 0.8 ms per 1024x1024 frame with Render() called every frame (due every 5th). */
 int mirt_accumulate_async(mirt_ctx* ctx, uint32_t n_calls);
 /* Launches anything deferred and waits for the GPU. */
 int mirt_synchronize(mirt_ctx* ctx);
