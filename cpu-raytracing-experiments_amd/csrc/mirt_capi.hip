@@ -579,6 +579,9 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 int mirt_set_camera(mirt_ctx* c, const float pos[3], const float orient_xyzw[4], float half_width, float half_height, float z, float exposure) {
 	if (!c) return MIRT_ERR_ARG;
 	if (!pos || !orient_xyzw) return fail(c, MIRT_ERR_ARG, "pos / orient is NULL");
+	if (c->have_camera && std::memcmp(c->camera.pos, pos, 12) == 0 && std::memcmp(c->camera.orient, orient_xyzw, 16) == 0 &&
+	    c->camera.half_width == half_width && c->camera.half_height == half_height && c->camera.z == z && c->camera.exposure == exposure)
+		return MIRT_OK;                                                                // unchanged (a host that re-sends it every frame): nothing to flush
 	{ const int fr = flush_deferred(c); if (fr) return fr; }                        // deferred accumulations belong to the camera they were issued under
 	for (int k = 0; k < 3; k++) c->camera.pos[k] = pos[k];
 	for (int k = 0; k < 4; k++) c->camera.orient[k] = orient_xyzw[k];

@@ -20,7 +20,7 @@ for label, fn, n in (("Accumulate(); Render() per frame", lambda: (r.Accumulate(
             if r.accumulations % 5 == 0: r.Render()
     elif label.startswith("AccumulateAsync(1); Render"):
         for _ in range(n):
-            r.AccumulateAsync(1); r.Render()
+            r.UpdateCamera(); r.AccumulateAsync(1); r.Render()      # as the binding in INTEGRATION.md does: camera re-sent every frame
         r.Synchronize()
     elif label.startswith("AccumulateAsync"):
         for _ in range(n): r.AccumulateAsync(1)

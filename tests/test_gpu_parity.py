@@ -359,6 +359,7 @@ def test_frame_loop_with_deferred_batches(mirt):
         if frame == 15:                                      # camera change WITHOUT reset: frames issued before keep the old camera
             sc.camera.pos = sc.camera.pos + np.array([0.0, 0.25, 0.0], dtype=np.float32)
             r.UpdateCamera(); o.update_camera()
+        r.UpdateCamera()                                     # the host mirror re-sends the camera before every Accumulate(): unchanged -> no flush
         r.AccumulateAsync(1); o.Accumulate(1)
         assert r.accumulations == o.accumulations            # issued frames are counted at once
         shown = r.Render()
