@@ -4,20 +4,32 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], "cfg2"): synthetic scene S(1000) (ground + 999 random spheres, 17
-materials, 15 emissive spheres, ambient 0.5), SAH BVH, MIS on, Policy.max_bounces = 5 (primary + 4 bounces),
-1024x1024 pixels, 64 accumulations.  One STEP = one such 64-accumulation pass (64 x Renderer::Accumulate()).
-N > 1: weak scaling — the image grows to N x 1024^2 pixels and rank r renders the r-th contiguous range of 4096
-tiles (no data-path collective; one RCCL gather of the accumulator slabs after the timed region, timed separately).
+Workload, for every N (BASELINE.json configs[3], "cfg4", SURVEY.md §8d — the config the metric is quoted on): the fixed
+4096x4096 image of the synthetic scene S(100000) (ground + 99 999 random spheres, 17 materials, 1562 emissive spheres,
+ambient 0), SAH BVH, MIS on, Policy.max_bounces = 9 (primary + 8 bounces).  One STEP = 64 x Renderer::Accumulate() over
+that image.  N = 1 renders the whole image on one GPU; N > 1 splits its tile rows over the ranks (interleaved rows,
+Renderer.hpp:75 is the axis being split): STRONG scaling, no data-path collective, one RCCL gather of the accumulator
+slabs after the timed region (timed separately).  --config cfg2|cfg3|cfg5 selects the other BASELINE configs, same rules.
 
-value = rays handed to closest-hit traversal by all ranks (Renderer.hpp:165: primary + extension rays; shadow rays
-are reported separately) / max-over-ranks wall time of the K timed steps, inputs resident in HBM.
+value = rays handed to closest-hit traversal by all ranks (Renderer.hpp:165: primary + extension rays; shadow rays are
+reported separately) / max-over-ranks wall time of the K timed steps, inputs resident in HBM, no profiling in that pass.
+
+roofline (N = 1): k_trace, the dominant kernel, is bound by VALU issue, not by HBM (its BVH bytes are served from LDS/L2).
+  * per-kernel durations: HIP events on the launch stream, in a second live pass with one batch in flight (policy.profile);
+  * VALU instructions, lane utilisation and HBM bytes (FETCH_SIZE / WRITE_SIZE): measured IN THIS RUN by short child
+    processes of this script under `rocprofv3 --pmc` (one batch each, separate passes as MI355X_MICROARCH.md prescribes),
+    started before this process touches the GPU.  Where rocprofv3 is unavailable those fields are null.
 """
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +37,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-LDS_PEAK_GBPS = 150000.0        # MI355X_MICROARCH.md §LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
+# VALU issue roof (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max
+# clock; the same product x 2 flop is the 157.3 TFLOP/s f32 vector peak).  Unit: 10^12 lane-instructions per second.
+VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
+SQ_COUNTERS = "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY"
 
 
 def algorithmic_bytes(c):
@@ -36,69 +51,139 @@ def algorithmic_bytes(c):
             + 28.125 * c["shadow_rays"] + 32 * (c["shadow_nodes"] + c["shadow_spheres"]))
 
 
-def shape_for(n_gpus, base=1024):
-    w = h = base
-    k = n_gpus
-    while k > 1:                      # double width, then height, ...: 1024x1024, 2048x1024, 2048x2048, 4096x2048
-        if w <= h:
-            w *= 2
-        else:
-            h *= 2
-        k //= 2
-    assert (w // 16) * (h // 16) == n_gpus * (base // 16) ** 2, "n_gpus must be a power of two"
-    return w, h
+def load_mirt():
+    return importlib.import_module("cpu-raytracing-experiments_amd")
 
 
-def cpu_baseline(mirt, scene_fn, cfg, log):
-    """The reference's own CPU path, as restated in oracle/ (the reference itself cannot be built here): stream-BVH
-    traversal (BVH.hpp:320-358) with the AVX2 8-ray sphere kernel, tiles over all host threads — on a bounded sample
-    (a few accumulations of the same 1024x1024 workload; rays/s does not depend on the accumulation count)."""
-    import oracle_binding as ob
-    # host threads this job may use: the GPU box gives a 1-GPU job a 16-CPU share, whatever the machine has
-    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
-    o = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_STREAM_BVH, threads=threads)
-    o.Resize(cfg["width"], cfg["height"])
-    t0 = time.perf_counter(); o.Accumulate(1); t1 = time.perf_counter() - t0
-    n = min(16, max(3, int(15.0 / max(t1, 1e-3))))
-    o.ResetAccumulator()
-    t0 = time.perf_counter(); o.Accumulate(n); dt = time.perf_counter() - t0
-    rays = o.counters()["rays"]
-    log(f"cpu baseline: {n} accumulations, {rays} rays in {dt:.2f}s on {threads} threads")
-    out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-           "sample": f"{n} of {cfg['spp']} accumulations of the same {cfg['width']}x{cfg['height']} S({cfg['n']}) workload, "
-                     f"oracle stream-BVH mode (reference BVH.hpp:320-358 restated; reference itself unbuildable here)"}
-    # the reference AS SHIPPED traverses nothing (#define USEBVH false, BVH.hpp:307): brute force over all spheres (SURVEY.md §8d asks for both)
+def make_renderer(mirt, cfg, device, **kw):
+    sc = mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])
+    return mirt.Renderer(sc, device=device, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True, use_bvh=bool(cfg["use_bvh"]), **kw)
+
+
+# ---- child process under rocprofv3 --pmc: one batch, one kernel on the GPU at a time ------------------------------------
+def pmc_child(args):
+    mirt = load_mirt()
+    cfg = dict(mirt.scene.CONFIGS[args.config])
+    r = make_renderer(mirt, cfg, 0, streams=1, max_batch=args.max_batch)
+    r.Resize(cfg["width"], cfg["height"])
+    batch = r.get_policy()["max_batch"]
+    r.Accumulate(batch)
+    c = r.counters()
+    print(json.dumps({"batch": batch, "rays": c["rays"], "shadow_rays": c["shadow_rays"]}), flush=True)
+    r.close()
+
+
+def run_pmc_pass(counters, args, log):
+    """`rocprofv3 --pmc <counters> -- python3 bench.py --pmc-child`: returns ({kernel class: {counter: sum, 'launches', 'us'}}, child info) or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_dir = tempfile.mkdtemp(prefix="mirt_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", *counters.split(), "--output-format", "csv", "-d", out_dir, "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", args.config, "--max-batch", str(args.max_batch)]
     try:
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        info = None
+        for line in p.stdout.splitlines():
+            if line.startswith("{") and '"batch"' in line:
+                info = json.loads(line)
+        files = glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or info is None or not files:
+            log(f"pmc pass [{counters}] failed (rc {p.returncode}): {p.stderr[-300:]}")
+            return None
+        agg = {}
+        for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            name = row["Kernel_Name"]
+            if "mirt::k_trace_fat" in name or "mirt::" not in name:
+                continue
+            klass = "trace" if "mirt::k_trace<" in name else "shade" if "mirt::k_shade<" in name else "other"
+            a = agg.setdefault(klass, {"launches": set(), "us": 0.0})
+            a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if row["Dispatch_Id"] not in a["launches"]:
+                a["launches"].add(row["Dispatch_Id"])
+                a["us"] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+        for a in agg.values():
+            a["launches"] = len(a["launches"])
+        return agg, info
+    except Exception as e:                                 # the bench line must not depend on the profiler
+        log(f"pmc pass [{counters}] skipped: {e}")
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def collect_pmc(args, log):
+    t0 = time.perf_counter()
+    out = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --pmc-child --config %s (one batch, one kernel at a time)" % args.config}
+    sq = run_pmc_pass(SQ_COUNTERS, args, log)
+    if sq is None:
+        return None
+    out["sq"], out["child"] = sq
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):              # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes
+        r = run_pmc_pass(name, args, log)
+        out[name] = r[0] if r else None
+    log(f"pmc passes took {time.perf_counter() - t0:.1f}s")
+    return out
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------
+def cpu_baseline(mirt, cfg, log):
+    """The reference's own CPU path as restated in oracle/ (the reference itself cannot be built here): stream-BVH traversal
+    (BVH.hpp:320-358) with the AVX2 8-ray sphere kernel, tiles over the host threads of this job — on a BOUNDED sample: the same
+    scene, camera and policy rendered at a reduced resolution (rays/s does not depend on the pixel count)."""
+    import oracle_binding as ob
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives a 1-GPU job a 16-CPU share
+    scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
+    o = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_STREAM_BVH, threads=threads)
+    w, h = min(cfg["width"], 512), min(cfg["height"], 512)
+    o.Resize(w, h)
+    t0 = time.perf_counter(); o.Accumulate(1); t1 = time.perf_counter() - t0
+    n = 1
+    if t1 < 6.0:                                            # grow the sample to ~15 s of CPU work
+        if cfg["width"] >= 1024 and cfg["height"] >= 1024 and t1 * 4 < 20.0:
+            w, h, t1 = 1024, 1024, t1 * 4
+            o.Resize(w, h)
+        n = max(1, min(16, int(15.0 / max(t1, 1e-3))))
+        o.ResetAccumulator()
+        t0 = time.perf_counter(); o.Accumulate(n); t1 = time.perf_counter() - t0
+    rays = o.counters()["rays"]
+    log(f"cpu baseline: {n} accumulation(s) at {w}x{h}, {rays} rays in {t1:.2f}s on {threads} threads")
+    out = {"value": rays / t1 / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+           "sample": f"{n} accumulation(s) of the same S({cfg['n']}) scene, camera and policy at {w}x{h} px (instead of {cfg['width']}x{cfg['height']}), oracle stream-BVH "
+                     f"mode (reference BVH.hpp:320-358 restated; the reference itself is unbuildable here), {threads}-thread share of the box's host cores"}
+    o.close()
+    try:    # the reference AS SHIPPED traverses nothing (#define USEBVH false, BVH.hpp:307): brute force over all spheres (SURVEY.md §8d asks for both)
         b = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_BRUTE, threads=threads)
-        win = 256 if cfg["n"] <= 2000 else 128 if cfg["n"] <= 20000 else 48          # cost grows with the sphere count: keep the sample to seconds
+        win = 256 if cfg["n"] <= 2000 else 128 if cfg["n"] <= 20000 else 48
         b.Resize(win, win)
         t0 = time.perf_counter(); b.Accumulate(2); dtb = time.perf_counter() - t0
         out["as_shipped_brute_force"] = {"value": b.counters()["rays"] / dtb / 1e6, "unit": "Mray/s", "cores": threads,
-                                         "sample": f"2 accumulations of a {win}x{win} window of the same scene and camera (USEBVH false: every ray tests all {cfg['n']} spheres)"}
+                                         "sample": f"2 accumulations at {win}x{win} px of the same scene and camera (USEBVH false: every ray tests all {cfg['n']} spheres)"}
         b.close()
-    except Exception as e:                                   # the headline baseline above is what the contract needs
+    except Exception as e:
         log(f"brute-force cpu baseline skipped: {e}")
-    o.close()
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=None, help="accumulations per step (default: cfg2's 64)")
+    ap.add_argument("--config", default="cfg4", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE config (default cfg4, the one the metric is quoted on). Every config keeps its own fixed image and splits its tile rows over the ranks")
+    ap.add_argument("--spp", type=int, default=64, help="accumulations (Renderer::Accumulate() calls) per step")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
     ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 32 M primary rays)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="BASELINE config. cfg2 (default, the metric's config) scales weakly: 1024x1024 px per GPU. The others keep their own image "
-                         "(cfg3 1920x1088, cfg4/5 4096x4096) and split its tile rows over the ranks (strong scaling); --spp bounds the accumulations per step")
+    ap.add_argument("--aux-steps", type=int, default=2, help="steps of the roofline passes (per-kernel HIP-event timing, counting replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-counts", action="store_true", help="skip the counting replay (roofline.achieved becomes null)")
+    ap.add_argument("--no-counts", action="store_true", help="skip the per-kernel timing and counting passes (roofline becomes null)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
-    import torch
-    mirt = importlib.import_module("cpu-raytracing-experiments_amd")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,6 +191,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    # PMC child passes first: nothing in this process has touched the GPU yet
+    pmc = None
+    if world == 1 and not args.no_pmc and not args.no_counts:
+        pmc = collect_pmc(args, log)
+
+    import torch
+    mirt = load_mirt()
     # Rehearsal knobs (single-GPU box): MIRT_BENCH_SHARE_GPU=1 puts every rank on cuda:0, MIRT_BENCH_BACKEND=gloo replaces RCCL
     # (which refuses two ranks on one device); the gather then stages through host memory.  Never set by the driver.
     backend = os.environ.get("MIRT_BENCH_BACKEND", "nccl")
@@ -122,30 +219,21 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     comm_device = "cuda" if backend == "nccl" else "cpu"
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
     cfg = dict(mirt.scene.CONFIGS[args.config])
-    weak = args.config == "cfg2"
-    if args.spp:
-        cfg["spp"] = args.spp
-    elif not weak:
-        cfg["spp"] = 64                                      # one step = 64 accumulations whatever the config's total
-    scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
-    width, height = shape_for(world, cfg["width"]) if weak else (cfg["width"], cfg["height"])
-    tiles = (width // 16) * (height // 16)
+    width, height = cfg["width"], cfg["height"]
     h_tiles, v_tiles = width // 16, height // 16
+    tiles = h_tiles * v_tiles
     first_row, row_stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)     # interleaved tile rows: every rank sees sky and ground alike
     count = n_rows * h_tiles
 
-    r = mirt.Renderer(scene_fn(), device=local_rank, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True,
-                      use_bvh=bool(cfg["use_bvh"]), profile=True, streams=args.streams, max_batch=args.max_batch)
+    r = make_renderer(mirt, cfg, local_rank, profile=False, streams=args.streams, max_batch=args.max_batch)
     n_streams = args.streams or 3
     r.Resize(width, height)
     if world > 1:
         r.SetTileRows(first_row, row_stride)
-    spp, K, W = cfg["spp"], args.steps, args.warmup
+    spp, K, W = args.spp, args.steps, args.warmup
+    batch = r.get_policy()["max_batch"]
+    log(f"{args.config}: {width}x{height}, S({cfg['n']}), {spp} accumulations/step, batches of {batch}, {count} of {tiles} tiles on this rank")
 
     def sync_all():
         r.Synchronize()
@@ -154,21 +242,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- timed pass: W warmup steps, then exactly K steps ----
+    # ---- timed pass: W warmup steps, then exactly K steps; no profiling, no counting ----
     for _ in range(W):
         r.Accumulate(spp)
-    r.kernel_times(reset=True)
+    rays0 = r.counters()["rays"]
     sync_all()
     t0 = time.perf_counter()
     for _ in range(K):
-        r.AccumulateAsync(spp)         # one step = one 64-accumulation call, enqueued like the reference's frame loop; the K steps are
-    sync_all()                         # bracketed by device synchronisation on both sides, not separated by it
+        r.AccumulateAsync(spp)         # the K steps are bracketed by device synchronisation on both sides, not separated by it
+    sync_all()
     elapsed = time.perf_counter() - t0
-    ktimes = r.kernel_times(reset=True)
+    rays_local = r.counters()["rays"] - rays0          # `rays` is counted by every launch (one atomic per kernel)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([float(rays_local)], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rays_total = int(t.item())
+    else:
+        rays_total = rays_local
 
     # ---- one gather of the accumulated radiance to rank 0 (RCCL over xGMI), outside the timed region ----
     gather_ms = None
@@ -183,114 +276,106 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
             assert tuple(full.shape) == (tiles, cfg["buckets"], 3, 256)
+        del full
 
-    # ---- roofline pass: the same W+K steps with ONE batch in flight, so every launch has the GPU to itself and its HIP-event
-    #      duration is the kernel's own (in the pipelined pass above a launch's duration includes time shared with the
-    #      other streams' kernels; those figures are reported as well, as "overlapped") ----
-    ktimes_serial = None
-    if n_streams != 1 and not args.no_counts:
+    # ---- roofline passes (rank 0's share of the image): the first `aux` steps after the warmup again, (a) with ONE batch in
+    #      flight and HIP events around every launch, so a launch's duration is the kernel's own; (b) with the kernels counting
+    #      the boxes and spheres they test ----
+    ktimes, counts = None, None
+    aux = max(1, min(args.aux_steps, K))
+    if not args.no_counts:
         r.set_policy(streams=1, profile=1, count_traffic=0)
         r.ResetAccumulator()
         for _ in range(W):
             r.Accumulate(spp)
         r.kernel_times(reset=True)
-        for _ in range(K):
+        for _ in range(aux):
             r.Accumulate(spp)
-        ktimes_serial = r.kernel_times(reset=True)
-
-    # ---- counting replay of the same steps: rays / nodes / spheres of exactly the timed accumulation indices ----
-    counts = None
-    if not args.no_counts:
+        ktimes = r.kernel_times(reset=True)
         r.set_policy(count_traffic=1, profile=0)
         r.ResetAccumulator()
         for _ in range(W):
             r.Accumulate(spp)
         c0 = r.counters()
-        for _ in range(K):
+        for _ in range(aux):
             r.Accumulate(spp)
         c1 = r.counters()
         counts = {k: c1[k] - c0[k] for k in c1}
-    rays_local = counts["rays"] if counts else None
-    if rays_local is None:                                  # rays are counted in every mode
-        c = r.counters(); rays_local = c["rays"] * K // (K + W)
-    rays_total = rays_local
-    if dist is not None:
-        t = torch.tensor([rays_local], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rays_total = int(t.item())
 
     if rank == 0:
         value = rays_total / elapsed / 1e6
         roofline = None
-        kt = ktimes_serial or ktimes
-        tr = kt["trace"]
-        if tr["launches"]:
-            avg_ms = tr["ms"] / tr["launches"]
-            roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": None, "peak": HBM_PEAK_GBPS, "peak_measured_copy": 6290.0, "unit": "GB/s", "frac": None,
-                        "traffic": None, "launches": tr["launches"], "avg_launch_ms": avg_ms,
-                        "measured_with": ("second live pass of the same steps with streams=1 (one kernel on the GPU at a time)" if ktimes_serial
-                                          else "the timed pass (streams=1)")}
-            if counts:
-                ab = algorithmic_bytes(counts)
-                ach = ab / (tr["ms"] * 1e-3) / 1e9
-                lds_bytes = 32.0 * (counts["nodes"] + counts["spheres"] + counts["shadow_nodes"] + counts["shadow_spheres"])
-                roofline["note"] = ("SURVEY.md §8d prices every BVH child box and sphere fetched at 32 B against HBM; k_trace serves them from the tree it stages "
-                                    "in LDS once per launch, so `achieved` can exceed the HBM peak: frac > 1 means HBM does not bound this kernel. Its real HBM "
-                                    "bytes per launch are `traffic` (PMC); the box/sphere part of the algorithmic bytes against the LDS roof is `lds`; the kernel "
-                                    "is bound by VALU issue and dependent LDS latency (DESIGN.md §4)")
-                roofline["lds"] = {"achieved": lds_bytes / (tr["ms"] * 1e-3) / 1e9, "peak": LDS_PEAK_GBPS, "unit": "GB/s",
-                                   "frac": lds_bytes / (tr["ms"] * 1e-3) / 1e9 / LDS_PEAK_GBPS}
-                roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, algorithmic_bytes_per_launch=ab / tr["launches"],
-                                nodes_per_ray=counts["nodes"] / counts["rays"], spheres_per_ray=counts["spheres"] / counts["rays"],
-                                nodes_per_shadow_ray=counts["shadow_nodes"] / max(counts["shadow_rays"], 1))
-                if ktimes_serial:
-                    ov = ktimes["trace"]
-                    roofline["overlapped"] = {"avg_launch_ms": ov["ms"] / ov["launches"], "achieved": ab / (ov["ms"] * 1e-3) / 1e9,
-                                              "frac": ab / (ov["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                              "note": f"same launches during the value pass, {n_streams} batches in flight: durations include time shared with other kernels"}
-            sh = kt.get("shade")
-            if counts and sh and sh["launches"]:
+        if ktimes and counts and ktimes["trace"]["launches"]:
+            tr, sh = ktimes["trace"], ktimes["shade"]
+            trace_s = tr["ms"] * 1e-3
+            traced = counts["rays"] + counts["shadow_rays"]
+            ab = algorithmic_bytes(counts)
+            roofline = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANE, "unit": "Tlane-inst/s", "frac": None, "traffic": None,
+                        "peak_definition": "256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz (= the 157.3 TFLOP/s f32 vector peak / 2 flop); a wave64 VALU instruction counts 64 lane slots",
+                        "launches": tr["launches"], "avg_launch_ms": tr["ms"] / tr["launches"],
+                        "measured_with": f"HIP events on the launch stream, second live pass of {aux} step(s) with one batch in flight",
+                        "traced_rays_per_launch": traced / tr["launches"],
+                        "boxes_per_ray": counts["nodes"] / counts["rays"], "spheres_per_ray": counts["spheres"] / counts["rays"],
+                        "boxes_per_shadow_ray": counts["shadow_nodes"] / max(counts["shadow_rays"], 1)}
+            hbm = {"bound": "hbm", "achieved": ab / trace_s / 1e9, "peak": HBM_PEAK_GBPS, "peak_measured_copy": 6290.0, "unit": "GB/s", "frac": ab / trace_s / 1e9 / HBM_PEAK_GBPS,
+                   "algorithmic_bytes_per_launch": ab / tr["launches"], "traffic": None,
+                   "note": "SURVEY.md §8d prices every BVH child box and sphere tested at 32 B against HBM; k_trace serves them from the tree top it stages in LDS and from L2, "
+                           "so this secondary figure may exceed 1: HBM does not bound the kernel. `traffic` = HBM bytes per launch from this run's FETCH_SIZE / WRITE_SIZE passes"}
+            if pmc and pmc.get("sq") and "trace" in pmc["sq"]:
+                q, ch = pmc["sq"]["trace"], pmc["child"]
+                ch_traced = ch["rays"] + ch["shadow_rays"]
+                valu_per_ray = q["SQ_INSTS_VALU"] / ch_traced
+                ach = valu_per_ray * traced * 64.0 / trace_s / 1e12
+                roofline.update(achieved=ach, frac=ach / VALU_PEAK_TLANE,
+                                valu_wave_instructions_per_traced_ray=valu_per_ray, salu_per_valu=q["SQ_INSTS_SALU"] / q["SQ_INSTS_VALU"],
+                                lane_utilisation=q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0),
+                                useful_frac=ach / VALU_PEAK_TLANE * q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0),
+                                wait_share=q["SQ_WAIT_ANY"] / max(q["SQ_WAVE_CYCLES"], 1.0),
+                                pmc={"source": pmc["command"], "batch": ch["batch"], "launches": q["launches"], "k_trace_ms_under_pmc": q["us"] / 1e3,
+                                     "traced_rays": ch_traced, "SQ_INSTS_VALU": q["SQ_INSTS_VALU"]},
+                                note="achieved = VALU wave-instructions per traced ray (SQ_INSTS_VALU of the k_trace dispatches of one batch, this run's rocprofv3 --pmc child pass) "
+                                     "x rays traced in the HIP-event pass x 64 lanes / k_trace time of that pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
+                                     "useful_frac = frac x lane_utilisation")
+                f, w_ = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+                if f and w_ and "trace" in f and "trace" in w_:
+                    # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact; both in KB
+                    hbm["traffic"] = (2.0 * f["trace"]["FETCH_SIZE"] + w_["trace"]["WRITE_SIZE"]) * 1024.0 / f["trace"]["launches"]
+                    hbm["traffic_fetch_bytes_x2"] = 2.0 * f["trace"]["FETCH_SIZE"] * 1024.0 / f["trace"]["launches"]
+                    hbm["traffic_write_bytes"] = w_["trace"]["WRITE_SIZE"] * 1024.0 / w_["trace"]["launches"]
+                    hbm["traffic_GBps"] = hbm["traffic"] / (q["us"] / q["launches"] * 1e-6) / 1e9
+                    roofline["traffic"] = hbm["traffic"]
+                    if "shade" in f and "shade" in w_:
+                        roofline["shade_traffic"] = (2.0 * f["shade"]["FETCH_SIZE"] + w_["shade"]["WRITE_SIZE"]) * 1024.0 / f["shade"]["launches"]
+            else:
+                roofline["note"] = "rocprofv3 --pmc child pass unavailable: VALU instruction counts (achieved, frac) and HBM traffic not measured in this run"
+            roofline["hbm"] = hbm
+            if sh["launches"]:
                 # second kernel: k_shade moves the ray streams and IS HBM-bound.  SURVEY.md §8d: 56 B read per ray shaded + 56 B written per
-                # extension ray + 24 B of accumulator RMW per terminated path
-                primary = K * spp * count * 256
-                sb = 56.0 * counts["rays"] + 56.0 * (counts["rays"] - primary) + 24.0 * counts["terminated"]
+                # extension ray + 24 B of accumulator RMW per terminated path (bounce 0 has no stream here: its rays are generated in the kernels)
+                primary = aux * spp * count * 256
+                sb = 56.0 * (counts["rays"] - primary) + 56.0 * (counts["rays"] - primary) + 24.0 * counts["terminated"]
                 roofline["shade"] = {"bound": "hbm", "kernel": "k_shade", "achieved": sb / (sh["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": sb / (sh["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches": sh["launches"], "avg_launch_ms": sh["ms"] / sh["launches"],
-                                     "note": "stream I/O only; the shadow-ray records it also writes (up to 68 B per NEE ray) are not in the §8d figure"}
-            if counts:
-                # all algorithmic bytes of the job (traversal + 56 B written and 56 B read per extension ray + 24 B per terminated path)
-                # over the job's wall time, against 8 TB/s per GPU
-                ext = counts["rays"] - K * spp * count * 256
-                job_bytes = algorithmic_bytes(counts) + 112.0 * ext + 24.0 * counts["terminated"]
-                roofline["whole_job"] = {"achieved": job_bytes * world / elapsed / 1e9, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                                         "frac": job_bytes / elapsed / 1e9 / HBM_PEAK_GBPS,
-                                         "note": "rank 0's algorithmic bytes x ranks over the timed pass (all kernels, batches overlapped)"}
-            traffic_file = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
-            if os.path.exists(traffic_file):
-                try:
-                    roofline["traffic"] = json.load(open(traffic_file))["kernels"]["mirt::k_trace<false>"]["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
-                except Exception:
-                    pass
+                                     "traffic": roofline.pop("shade_traffic", None),
+                                     "note": "§8d stream I/O of the extension rays only; the hit records it reads (8 B per ray) and the shadow-ray records it writes (32-68 B per NEE ray) are not in that figure"}
         out = {
             "metric": "Mray/s (primary+bounce)", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{args.config}: S({cfg['n']}) spheres + SAH BVH, MIS, Policy.max_bounces={cfg['max_bounces']} "
-                                    f"(primary+{cfg['max_bounces'] - 1} bounces), {spp} accumulations/step, "
-                                    + ("1024x1024 px per GPU" if weak else f"{width}x{height} px over all GPUs")), "image": f"{width}x{height}",
-                       "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
+            "config": {"workload": (f"{args.config}: {width}x{height} px, S({cfg['n']}) spheres + SAH BVH, MIS, Policy.max_bounces={cfg['max_bounces']} "
+                                    f"(primary+{cfg['max_bounces'] - 1} bounces), {cfg['buckets']} buckets, {spp} accumulations/step; fixed image, tile rows split over the GPUs"),
+                       "image": f"{width}x{height}", "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
                        "parallelism": f"tile rows interleaved over {world} GPUs, one RCCL gather" if world > 1 else "single GPU", "batches_in_flight": n_streams,
-                       "accumulations_per_batch": min(r.get_policy()["max_batch"], spp)},
+                       "accumulations_per_batch": min(batch, spp)},
             "rays_per_step": rays_total / K,
-            "shadow_rays_per_step": (counts["shadow_rays"] / K) if counts else None,
-            "kernel_ms_per_step": {k: v["ms"] / K for k, v in (ktimes_serial or ktimes).items() if v["launches"]},
+            "shadow_rays_per_step": (counts["shadow_rays"] / aux) if counts else None,
+            "kernel_ms_per_step": ({k: v["ms"] / aux for k, v in ktimes.items() if v["launches"]} if ktimes else None),
             "gather_ms": gather_ms,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(mirt, scene_fn, cfg, log)
-        elif world > 1:
+            out["cpu_baseline"] = cpu_baseline(mirt, cfg, log)
+        else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     r.close()

@@ -8,7 +8,8 @@
 //     q1 = (lo0.y, lo1.y, hi0.y, hi1.y)
 //     q2 = (lo0.z, lo1.z, hi0.z, hi1.z)
 //     q3 = (bits c0, bits c1, 0, 0)          child reference: inner -> record index,
-//                                            leaf -> kLeafBit | (prim_count-1) << 24 | first prim (BVH order)
+//                                            leaf -> kLeafBit | prim (BVH order); every leaf of the layout holds ONE prim
+//                                            (a caller's leaf of k prims becomes a small subtree of k leaves, split_multi_prim_leaves)
 // One 64-B fetch therefore serves both of a node's children (the reference stores them adjacently at
 // first_id, first_id+1 for the same reason).
 //
@@ -92,7 +93,25 @@ inline float half_ulp_at(float magnitude) {                // spacing of binary1
 	return std::ldexp(1.0f, e - 11);
 }
 
-inline uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafBit | ((count - 1u) << 24) | first; }
+inline uint32_t leaf_ref(uint32_t prim) { return kLeafBit | prim; }
+
+// The reference's builder only makes one-prim leaves (BVH.hpp:201-205) but its traversal loops over prim_count
+// (BVH.hpp:343-345), so a caller's tree may hold larger leaves.  The kernels only know one-prim leaves: a leaf of k prims
+// [first, first+k) is replaced by a median-split subtree over the same range (children appended at the end of the array,
+// so child indices stay larger than their parent's).  Boxes are recomputed from the prims by build_records anyway, and the
+// traversal result does not depend on the tree (DESIGN.md "Traversal semantics").
+inline void split_multi_prim_leaves(std::vector<mirt_bvh_node>& nodes) {
+	for (size_t i = 0; i < nodes.size(); i++) {                 // nodes appended below are visited as well
+		const uint32_t k = nodes[i].prim_count, first = nodes[i].first_id;
+		if (k <= 1) continue;
+		const uint32_t child = static_cast<uint32_t>(nodes.size()), half = k / 2;
+		mirt_bvh_node a = nodes[i], b = nodes[i];
+		a.first_id = first; a.prim_count = half;
+		b.first_id = first + half; b.prim_count = k - half;
+		nodes.push_back(a); nodes.push_back(b);
+		nodes[i].first_id = child; nodes[i].prim_count = 0;
+	}
+}
 
 // 32-B half-precision records from the 64-B ones.  Returns false (and leaves `out` empty) when binary16 is not adequate:
 // a coordinate beyond +-60000, or a leaf box whose smallest extent is under 8 quantisation steps (the box would grow by
@@ -145,15 +164,14 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 	recs.clear();
 	*max_depth_out = 0;
 	if (n_nodes == 0) return "";
-	if (n_prims > (1u << 24)) return "more than 2^24 spheres";
+	if (n_prims >= (1u << 31)) return "more than 2^31 spheres";
 	// conservative boxes, children before parents (children always have larger indices; validated by the caller)
 	std::vector<PadBox> box(n_nodes);
 	for (uint32_t k = n_nodes; k-- > 0;) {
 		const mirt_bvh_node& nd = nodes[k];
 		PadBox b{ { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
 		if (nd.prim_count != 0) {
-			if (nd.prim_count > 128) return "leaf with more than 128 prims";
-			if (prim_of_slot && nd.prim_count != 1) return "internal tree leaf with more than one prim";
+			if (nd.prim_count != 1) return "leaf with more than one prim (split_multi_prim_leaves first)";
 			for (uint32_t slot = nd.first_id; slot < nd.first_id + nd.prim_count; slot++) {
 				const uint32_t p = prim_of_slot ? (*prim_of_slot)[slot] : slot;
 				const float* c = prims[p].position;
@@ -180,7 +198,7 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		std::memcpy(&q[12 + child], &ref, 4);
 	};
 	const PadBox nothing{ { FLT_MAX, FLT_MAX, FLT_MAX }, { FLT_MAX, FLT_MAX, FLT_MAX } };   // degenerate box at +max: every slab test misses it
-	auto leaf_of = [&](const mirt_bvh_node& nd) { return leaf_ref(prim_of_slot ? (*prim_of_slot)[nd.first_id] : nd.first_id, nd.prim_count); };
+	auto leaf_of = [&](const mirt_bvh_node& nd) { return leaf_ref(prim_of_slot ? (*prim_of_slot)[nd.first_id] : nd.first_id); };
 	if (nodes[0].prim_count != 0) {                       // single-leaf tree: one record, second child empty
 		recs.assign(16, 0.0f);
 		put(0, 0, box[0], leaf_of(nodes[0]));
@@ -198,7 +216,10 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		for (uint32_t c = nodes[nd].first_id; c <= nodes[nd].first_id + 1; c++) {
 			depth[c] = depth[nd] + 1;
 			if (depth[c] > *max_depth_out) *max_depth_out = depth[c];
-			if (nodes[c].prim_count == 0) { rec_of[c] = static_cast<uint32_t>(order.size()); order.push_back(c); }
+			if (nodes[c].prim_count == 0) {
+				if (rec_of[c] != 0xffffffffu || order.size() >= n_nodes) return "node referenced by more than one parent";   // also bounds this loop
+				rec_of[c] = static_cast<uint32_t>(order.size()); order.push_back(c);
+			}
 		}
 	}
 	if (*max_depth_out >= MIRT_BVH_STACK) return "tree deeper than the 64-entry traversal stack (BVH.hpp:321)";

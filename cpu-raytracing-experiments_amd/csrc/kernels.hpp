@@ -47,7 +47,7 @@ struct SceneDev {
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
-	uint32_t multi_prim_leaves; // 1: some leaf holds more than one prim (only a caller's tree with policy.reference_tree can)
+	uint32_t _unused0;          // (leaves always hold one prim here: a caller's multi-prim leaves are split on the host, bvh_layout.hpp)
 	uint32_t stack16;           // 1: record indices fit 16 bits and the LDS stack holds u16 entries (binary16 records, <= 65535 of them)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
@@ -64,13 +64,16 @@ struct StreamBuf {
 	float *pdf;
 	uint32_t* path;             // (batch slot << 24) | local pixel index (tile_local*256 + ID); stands in for pixelID + seed[]
 };
-// RayStream<>::ShadowStream, DataStreams.hpp:113-126, plus the deferred-add operands.
+// RayStream<>::ShadowStream, DataStreams.hpp:113-126, plus the deferred-add operands.  A record is 32 B for the common case
+// (dir, tfar, NEE radiance, destination): the origin is the surviving ray's own (read from the next stream through `dest`;
+// stored here only for paths that Russian roulette ended), and the path radiance waits in the destination word itself.
 struct ShadowBuf {
-	float *px, *py, *pz, *dx, *dy, *dz, *tfar;
+	float *px, *py, *pz;        // origin — written only when dest is the accumulator (no surviving ray to share it with)
+	float *dx, *dy, *dz, *tfar;
 	float *sr, *sg, *sb;        // NEE radiance carried by the shadow ray
-	float *rr, *rg, *rb;        // path radiance before this bounce's adds
-	float *er, *eg, *eb;        // emissive add of this bounce (0 if none)
-	uint32_t* dest;             // next-stream slot, or kDestAccum | path id
+	float *rr, *rg, *rb;        // kDestFull records only: path radiance before this bounce's adds
+	float *er, *eg, *eb;        // kDestFull records only: emissive add of this bounce
+	uint32_t* dest;             // next-stream slot, or kDestAccum | path id; | kDestFull
 };
 struct FrameParams {
 	CameraParams cam;
@@ -87,6 +90,7 @@ struct FrameParams {
 	uint32_t buckets;
 	uint32_t mis;               // MIS && light_count > 0 (Q12 guard)
 	uint32_t n_lights;
+	float inv_n_pix, inv_h_tiles, inv_run_tiles;   // 1/n_pix, 1/h_tiles, 1/run_tiles for udiv_f (no integer division in the kernels)
 };
 struct DevCounters {
 	unsigned long long rays, shadow_rays, nodes, spheres, shadow_nodes, shadow_spheres, terminated, dropped;
@@ -340,7 +344,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	const bool any_leaf = __ballot(leaf_a | leaf_b) != 0ull;
 	float4 s_pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if (ALL_LDS && any_leaf) {
-		const uint32_t idx = (leaf_a | leaf_b) ? (cand & 0xffffffu) : 0u;     // lanes without a leaf child read sphere 0 (always valid: a leaf exists)
+		const uint32_t idx = (leaf_a | leaf_b) ? (cand & ~kLeafBit) : 0u;     // lanes without a leaf child read sphere 0 (always valid: a leaf exists)
 		if (ALL_LDS || idx < sc.lds_spheres) s_pre = to_float4(lds.spheres[idx]); else s_pre = sc.spheres[idx];
 	}
 	const RaySlab& rs = t.rs;
@@ -362,7 +366,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		for (int pass = 0; pass < 2; pass++) {
 			if (pass == 1 && __ballot(second) == 0ull) break;
 			if (pass == 1) { l0 = c1; on = second; }
-			const uint32_t first = l0 & 0xffffffu;
+			const uint32_t first = l0 & ~kLeafBit;
 			float4 s = s_pre;
 			const bool fetch = on & (!ALL_LDS || pass == 1 || l0 != cand);   // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
 			if (fetch) {                                                     // divergent on purpose: the load lands in s for these lanes only (a select would cost 4 + 4 moves)
@@ -371,25 +375,13 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			if (COUNT) n_spheres += on ? 1u : 0u;
 			if (ANYHIT) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
 			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
-			// leaves with more than one prim (never produced by the builders here; accepted from callers): remaining prims, rare path
-			const uint32_t extra = (sc.multi_prim_leaves && on) ? ((l0 >> 24) & 0x7fu) : 0u;
-			if (sc.multi_prim_leaves && __ballot(extra != 0u) != 0ull) {
-				for (uint32_t k = 1; k <= extra; k++) {
-					const uint32_t p = first + k;
-					if (COUNT) n_spheres++;
-					float4 s2;
-					if (ALL_LDS || p < sc.lds_spheres) s2 = to_float4(lds.spheres[p]); else s2 = sc.spheres[p];
-					if (ANYHIT) occluded = occluded || sphere_occludes_sel(s2, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar);
-					else sphere_closest_sel(true, s2, static_cast<int32_t>(p), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
-				}
-			}
 		}
 	}
 	// ---- next node: selects, plus one exec region each for the conditional stack write and read ----
 	ha = ha & !leaf_a; hb = hb & !leaf_b;
 	if (!ANYHIT) { ha = ha & (ta <= t.tfar); hb = hb & (tb <= t.tfar); }        // re-check against the shrunken tfar
 	const bool both = ha & hb, none = !(ha | hb);
-	const bool a_first = ANYHIT ? true : (ta <= tb);
+	const bool a_first = ta <= tb;                                            // any-hit rays too: an occluder is most likely close to the origin (the result does not depend on the order)
 	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one inner child is hit
 	const uint32_t far = a_first ? c1 : c0;                                   // inner reference = record index; depth < 64 is validated on the host
 	constexpr uint32_t lds_entries = (HALF && !ST16) ? kLdsStackWide : kLdsStack;
@@ -537,34 +529,61 @@ MIRT_DI bool bvh_all_in_lds(const SceneDev& sc) { return sc.lds_recs == sc.n_rec
 // RAY GENERATION — Renderer.hpp:97-127 (stream init is implicit: radiance 0 / throughput 1 are
 // supplied by k_shade<FIRST>, so only p, dir and the path id are written)
 // ------------------------------------------------------------------------------------------------
+// n / d for n < 2^31 and quotients below 2^20 (slots, tile rows, tile columns) with a precomputed 1/d: the float quotient is
+// within one of the truth, one correction step either way makes it exact (hipcc's u32 division is ~40 instructions).
+MIRT_DI uint32_t udiv_f(uint32_t n, uint32_t d, float inv_d, uint32_t& rem) {
+	uint32_t q = static_cast<uint32_t>(static_cast<float>(n) * inv_d);
+	int32_t r = static_cast<int32_t>(n - q * d);
+	if (r < 0) { q -= 1u; r += static_cast<int32_t>(d); }
+	else if (r >= static_cast<int32_t>(d)) { q += 1u; r -= static_cast<int32_t>(d); }
+	rem = static_cast<uint32_t>(r);
+	return q;
+}
 // Global LaunchIndex (Renderer.hpp:75,84-88) of this context's local tile.
-MIRT_DI uint32_t global_tile(uint32_t first_tile, uint32_t run_tiles, uint32_t stride_tiles, uint32_t local_tile) {
-	if (stride_tiles == 0u) return first_tile + local_tile;             // wave-uniform branch
+MIRT_DI uint32_t global_tile(uint32_t first_tile, uint32_t run_tiles, uint32_t stride_tiles, uint32_t local_tile) {     // k_resolve (once per pixel and frame)
+	if (stride_tiles == 0u) return first_tile + local_tile;
 	const uint32_t run = local_tile / run_tiles;
 	return first_tile + run * stride_tiles + (local_tile - run * run_tiles);
 }
-MIRT_DI uint32_t global_tile(const FrameParams& fp, uint32_t local_tile) { return global_tile(fp.first_tile, fp.run_tiles, fp.stride_tiles, local_tile); }
+MIRT_DI uint32_t global_tile(const FrameParams& fp, uint32_t local_tile) {
+	if (fp.stride_tiles == 0u) return fp.first_tile + local_tile;             // wave-uniform branch
+	uint32_t in_run;
+	const uint32_t run = udiv_f(local_tile, fp.run_tiles, fp.inv_run_tiles, in_run);
+	return fp.first_tile + run * fp.stride_tiles + in_run;
+}
 MIRT_DI uint32_t path_seed(const FrameParams& fp, uint32_t pix) {      // seed[ID], Renderer.hpp:107 (wraps like the int32 cast)
 	return (global_tile(fp, pix >> 8) * kTileSize + (pix & 255u)) * (fp.max_bounces * 2u + 1u);
 }
+// RAY GENERATION, Renderer.hpp:97-127, for stream index i = slot * n_pix + pix of a batch: path id and direction (the origin
+// is cam.pos).  Bounce 0 has no ray stream in HBM: k_trace<PRIMARY> and k_shade<FIRST> both derive the ray from its index
+// (~90 VALU instructions each, against 28 B written + 52 B read per primary ray).
+MIRT_DI void primary_ray(const FrameParams& fp, uint32_t i, uint32_t& path, float& dx, float& dy, float& dz) {
+	uint32_t pix;
+	const uint32_t slot = udiv_f(i, fp.n_pix, fp.inv_n_pix, pix);
+	const uint32_t tile = global_tile(fp, pix >> 8);
+	const uint32_t ID = pix & 255u;
+	uint32_t col;
+	const uint32_t row = udiv_f(tile, fp.h_tiles, fp.inv_h_tiles, col);
+	const int32_t x = static_cast<int32_t>(kTileRoot * col + (ID & 15u));
+	const int32_t y = static_cast<int32_t>(kTileRoot * row + (ID >> 4));
+	const uint32_t acc = fp.acc_base + slot + 1u;                           // ++accumulations, Renderer.hpp:74
+	uint32_t rng = hash_2d(acc, (tile * kTileSize + ID) * (fp.max_bounces * 2u + 1u));
+	const float s0 = rand_unit_float(rng);
+	const float s1 = rand_unit_float(rng);
+	const f3 d = camera_ray_dir(fp.cam, x, y, s0, s1);
+	path = (slot << 24) | pix;
+	dx = d.x; dy = d.y; dz = d.z;
+}
+// The same rays written out as a stream (mirt_debug_raygen only).
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out, uint32_t* stream_count) {
 	const uint32_t total = fp.n_pix * fp.batch_n;
 	if (blockIdx.x == 0 && threadIdx.x == 0) stream_count[0] = total;
 	for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-		const uint32_t slot = i / fp.n_pix;
-		const uint32_t pix = i - slot * fp.n_pix;
-		const uint32_t tile = global_tile(fp, pix >> 8);
-		const uint32_t ID = pix & 255u;
-		const int32_t x = static_cast<int32_t>(kTileRoot * (tile % fp.h_tiles) + (ID & 15u));
-		const int32_t y = static_cast<int32_t>(kTileRoot * (tile / fp.h_tiles) + (ID >> 4));
-		const uint32_t acc = fp.acc_base + slot + 1u;                       // ++accumulations, Renderer.hpp:74
-		uint32_t rng = hash_2d(acc, path_seed(fp, pix));
-		const float s0 = rand_unit_float(rng);
-		const float s1 = rand_unit_float(rng);
-		const f3 d = camera_ray_dir(fp.cam, x, y, s0, s1);
+		uint32_t path; float dx, dy, dz;
+		primary_ray(fp, i, path, dx, dy, dz);
 		out.px[i] = fp.cam.pos[0]; out.py[i] = fp.cam.pos[1]; out.pz[i] = fp.cam.pos[2];
-		out.dx[i] = d.x; out.dy[i] = d.y; out.dz[i] = d.z;
-		out.path[i] = (slot << 24) | pix;
+		out.dx[i] = dx; out.dy[i] = dy; out.dz[i] = dz;
+		out.path[i] = path;
 	}
 }
 
@@ -604,29 +623,46 @@ MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, floa
 }
 // Where a finished shadow ray's radiance goes.  The adds that had to wait for the occlusion test — (R + unoccluded NEE) +
 // emissive, the reference's order (Renderer.hpp:307-311, then 339-341 / 348-350) — are made by the lane that traced the
-// ray, straight into the next stream's radiance planes or the accumulator: k_trace is VALU-bound, so the ~16 memory
+// ray, straight into the next stream's radiance planes or the accumulator: k_trace is VALU-bound, so the few memory
 // instructions per shadow ray ride along for free, where a separate pass over the shadow stream cost 4.8 ms per cfg2 step.
+//   * light record (the common case: the hit was not emissive): k_shade has already put R where the result belongs — the
+//     surviving ray's radiance word, or the path's own word of the zeroed contribution buffer — so an occluded ray (most of
+//     them) touches nothing and an unoccluded one adds its NEE radiance to that word: R + S, and the emissive term is +0;
+//   * kDestFull record (emissive hit, or a path that ended while batches add straight into the accumulator, whose words hold
+//     earlier samples): R and E travel in the record and (R + S) + E is formed here.
 // occ != nullptr (mirt_debug_trace_shadow): only the occlusion flag is stored.
-constexpr uint32_t kDestHasE = 0x40000000u;     // shadow record carries an emissive add (else it is +0 and the planes are not touched)
+constexpr uint32_t kDestFull = 0x40000000u;
+constexpr uint32_t kDestSlot = 0x3fffffffu;     // stream slots stay below 2^30 (capacity check in mirt_capi.hip); path ids use bits 0-29 too (slot < 64)
 struct ShadowSink {
 	float *rr, *rg, *rb;        // radiance planes of the stream k_shade reads next
+	const float *px, *py, *pz;  // its origin planes (shared with the shadow rays of the surviving paths)
 	float* accum;
 	uint32_t acc_base, buckets;
 	uint32_t* occ;
-	uint32_t r_zero;            // shadow rays of bounce 0: the path radiance before the bounce is +0 and is not stored
 };
+MIRT_DI void shadow_origin(const ShadowBuf& sh, const ShadowSink& sink, uint32_t i, float& px, float& py, float& pz) {
+	if (sink.occ) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; return; }        // stage-level entry point: plain ray list
+	const uint32_t dw = sh.dest[i];
+	if (dw & kDestAccum) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; }
+	else { const uint32_t d = dw & kDestSlot; px = sink.px[d]; py = sink.py[d]; pz = sink.pz[d]; }
+}
 MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t i, bool occluded, uint32_t& c_term) {
 	if (sink.occ) { sink.occ[i] = occluded ? 1u : 0u; return; }
-	const uint32_t dest_word = sh.dest[i];
-	f3 R{ 0.0f, 0.0f, 0.0f }, E{ 0.0f, 0.0f, 0.0f };
-	if (!sink.r_zero) R = { sh.rr[i], sh.rg[i], sh.rb[i] };
-	const f3 S{ sh.sr[i], sh.sg[i], sh.sb[i] };
-	if (dest_word & kDestHasE) E = { sh.er[i], sh.eg[i], sh.eb[i] };
-	const uint32_t dest = dest_word & ~kDestHasE;
-	R.x = occluded ? R.x : R.x + S.x; R.y = occluded ? R.y : R.y + S.y; R.z = occluded ? R.z : R.z + S.z;
-	R.x += E.x; R.y += E.y; R.z += E.z;
-	if (dest & kDestAccum) { c_term++; accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), R.x, R.y, R.z); }
-	else { sink.rr[dest] = R.x; sink.rg[dest] = R.y; sink.rb[dest] = R.z; }
+	const uint32_t dw = sh.dest[i];
+	const uint32_t dest = dw & (kDestSlot | kDestAccum);
+	if (dw & kDestAccum) c_term++;
+	if (dw & kDestFull) {
+		f3 R{ sh.rr[i], sh.rg[i], sh.rb[i] };
+		const f3 E{ sh.er[i], sh.eg[i], sh.eb[i] };
+		if (!occluded) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }
+		R.x += E.x; R.y += E.y; R.z += E.z;
+		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), R.x, R.y, R.z);
+		else { sink.rr[dest] = R.x; sink.rg[dest] = R.y; sink.rb[dest] = R.z; }
+	} else if (!occluded) {
+		const f3 S{ sh.sr[i], sh.sg[i], sh.sb[i] };
+		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), S.x, S.y, S.z);   // word = R + S
+		else { sink.rr[dest] += S.x; sink.rg[dest] += S.y; sink.rb[dest] += S.z; }
+	}
 }
 
 // INTERSECTION + SHADOW RAY TRACING in one launch: Traverse (BVH.hpp:309-360) for the rays of bounce b and
@@ -635,15 +671,16 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 // persistent kernel halves the number of tails: a wave that runs out of closest-hit rays moves on to the shadow queue.
 // Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
 // 8 waves/SIMD (= two 16-wave workgroups per CU, the LDS plan of the binary16 layout) caps the kernel at 64 VGPRs.
-template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
+// PRIMARY = bounce 0: the rays are generated from their stream index (primary_ray), nothing is read; no shadow rays are pending.
+template <bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FrameParams fp,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                        const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
                                                        ShadowBuf sh, ShadowSink sink,
                                                        const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
                                                        DevCounters* ctr) {
 	extern __shared__ float4 lds[];
-	const uint32_t nc = *closest_count, ns = *shadow_count;
+	const uint32_t nc = PRIMARY ? fp.n_pix * fp.batch_n : *closest_count, ns = PRIMARY ? 0u : *shadow_count;
 	if (nc + ns == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		if (nc) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));
@@ -655,14 +692,16 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
 		const TraceLds tl = stage_bvh(sc, lds);
 		{
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-				px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; tf = MIRT_FLT_MAX;   // hit reset, Renderer.hpp:150-158
+				if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
+				else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
+				tf = MIRT_FLT_MAX;                                                 // hit reset, Renderer.hpp:150-158
 			};
 			auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
 			trace_queue<false, COUNT>(sc, tl, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
-		{
+		if (!PRIMARY) {
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-				px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
+				shadow_origin(sh, sink, i, px, py, pz); dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 			};
 			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { shadow_finish(sh, sink, i, occluded, c_term); };
 			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
@@ -673,7 +712,10 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
 			const uint32_t i = base + threadIdx.x;
 			const bool active = i < nc;
 			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
-			if (active) { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
+			if (active) {
+				if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
+				else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
+			}
 			float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
 			int32_t prim = -1;
 			if (sc.use_bvh == 0) traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
@@ -683,7 +725,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
 			const uint32_t i = base + threadIdx.x;
 			const bool active = i < ns;
 			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
-			if (active) { px = sh.px[i]; py = sh.py[i]; pz = sh.pz[i]; dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
+			if (active) { shadow_origin(sh, sink, i, px, py, pz); dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
 			bool occluded = false;
 			int32_t dummy = -1;
 			if (sc.use_bvh == 0) occluded = traverse_brute<true, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, dummy, s_spheres);
@@ -697,8 +739,8 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc,
 // Fat rays (see trav_begin): one workgroup per ray runs the reference's brute-force loops over ALL prims —
 // intersect_prims (BVH.hpp:236-288; closest = lexicographic minimum of (dist, prim index), i.e. the ascending strict-'<' scan)
 // for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
-template <bool COUNT>
-__global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
+template <bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
                                                     ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr) {
 	__shared__ float s_t[16];
 	__shared__ int32_t s_p[16];
@@ -706,7 +748,9 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, f
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
 	for (uint32_t k = blockIdx.x; k < nc; k += gridDim.x) {
 		const uint32_t i = fat_closest.rays[k];
-		const float px = in.px[i], py = in.py[i], pz = in.pz[i], dx = in.dx[i], dy = in.dy[i], dz = in.dz[i];
+		float px, py, pz, dx, dy, dz;
+		if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
+		else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
 		float tfar = MIRT_FLT_MAX; int32_t prim = -1;
 		for (uint32_t p = threadIdx.x; p < sc.n_spheres; p += blockDim.x) sphere_closest(sc.spheres[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, tfar, prim);
 		// lexicographic (dist, prim) minimum across the workgroup; prim -1 = no hit, always loses (its tfar is FLT_MAX and every hit is < FLT_MAX)
@@ -730,7 +774,9 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, StreamBuf in, f
 	}
 	for (uint32_t k = blockIdx.x; k < ns; k += gridDim.x) {
 		const uint32_t i = fat_shadow.rays[k];
-		const float px = sh.px[i], py = sh.py[i], pz = sh.pz[i], dx = sh.dx[i], dy = sh.dy[i], dz = sh.dz[i], tfar = sh.tfar[i];
+		float px, py, pz;
+		shadow_origin(sh, sink, i, px, py, pz);
+		const float dx = sh.dx[i], dy = sh.dy[i], dz = sh.dz[i], tfar = sh.tfar[i];
 		bool occ = false;
 		for (uint32_t p = threadIdx.x; p < sc.n_spheres && !occ; p += blockDim.x) occ = sphere_occludes(sc.spheres[p], px, py, pz, dx, dy, dz, tfar);
 		const int any = __syncthreads_or(occ ? 1 : 0);
@@ -776,7 +822,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
                                                   const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
                                                   uint32_t* stream_count, uint32_t* shadow_count, float* __restrict__ accum, DevCounters* ctr) {
-	const uint32_t n = stream_count[bounce];
+	const uint32_t n = FIRST ? fp.n_pix * fp.batch_n : stream_count[bounce];
 	uint32_t* next_count = &stream_count[bounce + 1];
 	uint32_t* sh_count = &shadow_count[bounce];
 	const bool last_bounce = !(bounce < fp.max_bounces - 1u);                 // Renderer.hpp:358
@@ -788,7 +834,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	uint32_t c_term = 0, c_drop = 0, parity = 0;
 	if (blockIdx.x * kShadeBlock >= n) return;
 	for (uint32_t m = threadIdx.x; m < sc.n_mat; m += kShadeBlock) { s_albedo[m] = sc.mat_albedo[m]; s_emission[m] = sc.mat_emission[m]; }
-	// (made visible by the first barrier of block_compact)
+	__syncthreads();            // the table is read by every wave in phase 2; k_shade<FIRST> reaches no other barrier before that (the early return above is block-uniform)
 
 	for (uint32_t base = blockIdx.x * kShadeBlock; base < n; base += gridDim.x * kShadeBlock, parity ^= 1u) {
 		// ---- phase 1, one lane per ray of the stream: misses end here; hits are only listed ----
@@ -801,12 +847,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 					// MISS SHADER, Renderer.hpp:408-420 (Q10: throughput.r scales all three channels)
 					f3 R{0.0f, 0.0f, 0.0f};
 					float thr_x = 1.0f;
-					if (!FIRST) { R = { in.rr[i], in.rg[i], in.rb[i] }; thr_x = in.tr[i]; }
+					uint32_t mpath; f3 md;
+					if (FIRST) primary_ray(fp, i, mpath, md.x, md.y, md.z);
+					else { R = { in.rr[i], in.rg[i], in.rb[i] }; thr_x = in.tr[i]; mpath = in.path[i]; }
 					if (sc.has_ambient) {
-						const f3 sky = sky_eval(sc, in.dx[i], in.dy[i], in.dz[i]);
+						if (!FIRST) md = { in.dx[i], in.dy[i], in.dz[i] };
+						const f3 sky = sky_eval(sc, md.x, md.y, md.z);
 						R.x += thr_x * sky.x; R.y += thr_x * sky.y; R.z += thr_x * sky.z;
 					}
-					accumulate_add(accum, accum_index(fp, in.path[i]), R.x + 0.0f, R.y + 0.0f, R.z + 0.0f);   // ACCUMULATION, Renderer.hpp:424-430 (+ the zero emissive term)
+					accumulate_add(accum, accum_index(fp, mpath), R.x + 0.0f, R.y + 0.0f, R.z + 0.0f);   // ACCUMULATION, Renderer.hpp:424-430 (+ the zero emissive term)
 					c_term++;
 				} else if (last_bounce) {
 					c_drop++;                                                         // Q5: still alive after the last bounce -> never accumulated
@@ -826,8 +875,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		float npdf = 0.0f, light_distance = 0.0f;
 		if (FIRST ? is_hit : threadIdx.x < n_hits) {
 			const uint32_t i = FIRST ? base + threadIdx.x : hit_list[threadIdx.x];
-			path = in.path[i];
-			const f3 D{ in.dx[i], in.dy[i], in.dz[i] };
+			f3 D;
+			if (FIRST) primary_ray(fp, i, path, D.x, D.y, D.z);                  // bounce 0 has no stream: the ray is a function of its index
+			else { path = in.path[i]; D = { in.dx[i], in.dy[i], in.dz[i] }; }
 			float pdf_in = 0.0f;
 			if (!FIRST) {
 				R = { in.rr[i], in.rg[i], in.rb[i] };
@@ -840,7 +890,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 				const float depth = tfar_in[i];
 				const float4 hs = sc.spheres[prim];
 				const int32_t mat = sc.prim_mat[prim];
-				const f3 O{ in.px[i], in.py[i], in.pz[i] };
+				const f3 O = FIRST ? f3{ fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2] } : f3{ in.px[i], in.py[i], in.pz[i] };
 				const f3 hit{ O.x + D.x * depth, O.y + D.y * depth, O.z + D.z * depth };
 				f3 N = normalize3(f3{ hit.x - hs.x, hit.y - hs.y, hit.z - hs.z });
 				if (dot3(N, D) >= 0.0f) N = f3{ -N.x, -N.y, -N.z };
@@ -926,6 +976,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		// ---- stream compaction: wave64 ballot + mbcnt prefix inside each wave, one atomic per workgroup and stream ----
 		uint32_t slot, sslot;
 		block_append2(survive, has_shadow, next_count, sh_count, append_scratch, parity, slot, sslot);
+		// (R + unoccluded NEE) + E is finished by k_trace's shadow_finish once the occlusion is known.  Non-emissive hits (E = +0)
+		// leave R where that result belongs and send a light record; the others send R and E along (kDestFull).
+		const bool direct = fp.idx_base != 0xffffffffu;                          // paths add straight into accumulator words that hold earlier samples
+		const bool full = has_shadow & (has_E | (terminated & direct));
 		if (survive) {
 			out.px[slot] = P.x; out.py[slot] = P.y; out.pz[slot] = P.z;
 			out.dx[slot] = ndir.x; out.dy[slot] = ndir.y; out.dz[slot] = ndir.z;
@@ -934,18 +988,20 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			out.path[slot] = path;
 		}
 		if (has_shadow) {
-			// radiance is finalised by k_trace (shadow_finish) once it knows the occlusion: (R + unoccluded NEE) + E
-			sh.px[sslot] = P.x; sh.py[sslot] = P.y; sh.pz[sslot] = P.z;
+			if (!survive) { sh.px[sslot] = P.x; sh.py[sslot] = P.y; sh.pz[sslot] = P.z; }          // else: the surviving ray's origin, found through dest
 			sh.dx[sslot] = L.x; sh.dy[sslot] = L.y; sh.dz[sslot] = L.z;
 			sh.tfar[sslot] = light_distance;
 			sh.sr[sslot] = srad.x; sh.sg[sslot] = srad.y; sh.sb[sslot] = srad.z;
-			if (!FIRST) { sh.rr[sslot] = R.x; sh.rg[sslot] = R.y; sh.rb[sslot] = R.z; }      // bounce 0: R is +0 (ShadowSink::r_zero)
-			if (has_E) { sh.er[sslot] = E.x; sh.eg[sslot] = E.y; sh.eb[sslot] = E.z; }       // else +0: not stored (kDestHasE clear)
-			sh.dest[sslot] = (survive ? slot : (kDestAccum | path)) | (has_E ? kDestHasE : 0u);
-		} else if (survive || terminated) {
-			const f3 Rf{ R.x + E.x, R.y + E.y, R.z + E.z };                       // E is +0 when the hit is not emissive (exact no-op)
+			if (full) {
+				sh.rr[sslot] = R.x; sh.rg[sslot] = R.y; sh.rb[sslot] = R.z;
+				sh.er[sslot] = E.x; sh.eg[sslot] = E.y; sh.eb[sslot] = E.z;
+			}
+			sh.dest[sslot] = (survive ? slot : (kDestAccum | path)) | (full ? kDestFull : 0u);
+		}
+		if ((survive | terminated) & !full) {
+			const f3 Rf{ R.x + E.x, R.y + E.y, R.z + E.z };                       // E is +0 when the hit is not emissive (exact no-op); with a light record pending E is +0 too
 			if (survive) { out.rr[slot] = Rf.x; out.rg[slot] = Rf.y; out.rb[slot] = Rf.z; }
-			else accumulate_add(accum, accum_index(fp, path), Rf.x, Rf.y, Rf.z);   // ACCUMULATION, Renderer.hpp:424-430
+			else accumulate_add(accum, accum_index(fp, path), Rf.x, Rf.y, Rf.z);   // ACCUMULATION, Renderer.hpp:424-430 (a pending light record adds its NEE term to the same word)
 		}
 		c_term += (terminated && !has_shadow) ? 1u : 0u;
 	}

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -103,6 +104,8 @@ struct mirt_ctx {
 	uint64_t batch_seq = 0;
 
 	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
+	// launch-shape knobs for measurements (profiles/experiments/*): MIRT_TUNE_TRACE_WGS / MIRT_TUNE_SHADE_WGS = workgroups per CU
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -122,7 +125,7 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 // Accumulations traced together as one batch.  A trace launch ends in a ~0.2 ms tail while its longest rays finish, so
 // launches want to be large: by default a batch carries about 32 M primary rays (cfg2: 32 accumulations of 1024^2),
 // at most kMaxBatch (the path id keeps the slot in 7 bits).
-constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestHasE)
+constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestFull)
 constexpr uint64_t kBatchRays = 32ull << 20;
 uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
@@ -157,7 +160,7 @@ uint32_t stage_budget(bool half, bool stack16) { return half ? (stack16 ? 48u * 
 uint32_t trace_lds(const mirt_ctx* c) { return c->policy.use_bvh ? c->trace_lds_bytes + stack_bytes(c) : kBruteChunk * 16u; }
 uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 	uint32_t per_cu = kLdsPerCu / trace_lds(c);
-	if (per_cu > 2) per_cu = 2;                                       // 2 x 1024 threads = 32 waves, the CU's limit
+	if (per_cu > c->tune_trace_wgs) per_cu = c->tune_trace_wgs;      // 2 x 1024 threads = 32 waves, the CU's limit
 	if (per_cu < 1) per_cu = 1;
 	uint64_t blocks = (work_items + kTraceBlock - 1) / kTraceBlock;
 	const uint64_t cap = static_cast<uint64_t>(c->n_cu) * per_cu;
@@ -179,7 +182,7 @@ int ensure_streams(mirt_ctx* c) {
 	const uint64_t cap64 = n_pix * batch_limit(c);
 	if (cap64 == 0) return MIRT_OK;
 	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
-	if (cap64 >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);
+	if (cap64 > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
 	const uint32_t cap = static_cast<uint32_t>(cap64);
 	const uint32_t nb = c->policy.max_bounces;
 	const uint32_t want = wanted_slots(c);
@@ -289,6 +292,9 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	fp.buckets = c->policy.buckets;
 	fp.n_lights = c->scene.n_lights;
 	fp.mis = (c->policy.mis && c->scene.n_lights > 0) ? 1u : 0u;       // Q12 guard
+	fp.inv_n_pix = fp.n_pix ? 1.0f / static_cast<float>(fp.n_pix) : 0.0f;
+	fp.inv_h_tiles = fp.h_tiles ? 1.0f / static_cast<float>(fp.h_tiles) : 0.0f;
+	fp.inv_run_tiles = 1.0f / static_cast<float>(fp.run_tiles);
 	return fp;
 }
 
@@ -323,16 +329,14 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	SceneDev sc = c->scene;
 	sc.use_bvh = c->policy.use_bvh;
 	const bool count = c->policy.count_traffic != 0;
-	const uint32_t grid = grid_for(c, total);
 	const uint32_t tgrid = trace_grid(c, total);
-	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 3u));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
+	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
 	const uint32_t tlds = trace_lds(c);
 
 	if (pipelined && sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));   // the slot's previous batch has been merged: buffers are free
 	if (contrib) HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, contrib_floats * sizeof(float), st));
 	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t), st));
-	{ Bracket t(c, MIRT_K_RAYGEN, st);
-	  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, st, fp, sl.stream_buf[0], stream_count); }
+	// bounce 0 has no ray stream: k_trace<PRIMARY> and k_shade<FIRST> derive the camera ray from its index (RAY GENERATION, Renderer.hpp:113-127)
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
 		const StreamBuf& in = sl.stream_buf[bounce & 1u];
 		const StreamBuf& out = sl.stream_buf[(bounce & 1u) ^ 1u];
@@ -343,15 +347,15 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-		  const ShadowSink sink{ in.rr, in.rg, in.rb, accum, fp.idx_base, fp.idx_buckets, nullptr, bounce == 1 ? 1u : 0u };
-		  if (count) hipLaunchKernelGGL(k_trace<true>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
-		  else       hipLaunchKernelGGL(k_trace<false>, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                                sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
-		  if (sc.use_bvh) {                                           // the few rays too "fat" for the tree: brute force, one workgroup each
-		    if (count) hipLaunchKernelGGL(k_trace_fat<true>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
-		    else       hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, st, sc, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
-		  } }
+		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, nullptr };
+		  auto launch_trace = [&](auto kernel, auto fat_kernel) {
+		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
+		                       sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
+		    // the few rays too "fat" for the tree: brute force, one workgroup each
+		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(64), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
+		  };
+		  if (bounce == 0) { if (count) launch_trace(k_trace<true, true>, k_trace_fat<true, true>); else launch_trace(k_trace<false, true>, k_trace_fat<false, true>); }
+		  else             { if (count) launch_trace(k_trace<true, false>, k_trace_fat<true, false>); else launch_trace(k_trace<false, false>, k_trace_fat<false, false>); } }
 		{ Bracket t(c, MIRT_K_SHADE, st);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
@@ -418,6 +422,8 @@ int mirt_create(int device, mirt_ctx** out) {
 	if (e != hipSuccess) return fail(nullptr, MIRT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
 	mirt_ctx* c = new mirt_ctx();
 	c->device = device;
+	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
+	if (const char* e = std::getenv("MIRT_TUNE_SHADE_WGS")) c->tune_shade_wgs = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 16));
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -473,11 +479,18 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	}
 	for (uint32_t i = 0; i < n_lights; i++)
 		if (lights[i] < 0 || static_cast<uint32_t>(lights[i]) >= n_spheres) return fail(c, MIRT_ERR_ARG, "light %u: index out of range", i);
-	for (uint32_t i = 0; i < n_nodes; i++) {
-		const mirt_bvh_node& nd = nodes[i];
-		if (nd.prim_count == 0) {
-			if (nd.first_id <= i || static_cast<uint64_t>(nd.first_id) + 1 >= n_nodes) return fail(c, MIRT_ERR_ARG, "node %u: child index %u invalid", i, nd.first_id);
-		} else if (static_cast<uint64_t>(nd.first_id) + nd.prim_count > n_spheres) return fail(c, MIRT_ERR_ARG, "node %u: prim range out of bounds", i);
+	{
+		// children point forward and every node has at most one parent: the node array is a forest, so the breadth-first
+		// re-layout (bvh_layout.hpp) visits at most n_nodes nodes (shared children would make it grow like Fibonacci numbers)
+		std::vector<uint8_t> has_parent(n_nodes, 0);
+		for (uint32_t i = 0; i < n_nodes; i++) {
+			const mirt_bvh_node& nd = nodes[i];
+			if (nd.prim_count == 0) {
+				if (nd.first_id <= i || static_cast<uint64_t>(nd.first_id) + 1 >= n_nodes) return fail(c, MIRT_ERR_ARG, "node %u: child index %u invalid", i, nd.first_id);
+				if (has_parent[nd.first_id] || has_parent[nd.first_id + 1]) return fail(c, MIRT_ERR_ARG, "node %u: child pair %u is referenced by more than one parent", i, nd.first_id);
+				has_parent[nd.first_id] = has_parent[nd.first_id + 1] = 1;
+			} else if (static_cast<uint64_t>(nd.first_id) + nd.prim_count > n_spheres) return fail(c, MIRT_ERR_ARG, "node %u: prim range out of bounds", i);
+		}
 	}
 	if (n_spheres && n_nodes == 0) return fail(c, MIRT_ERR_ARG, "spheres without BVH nodes");
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -526,7 +539,9 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	} else {
 		if (c->policy.reference_tree || n_spheres == 0) {
 			// traverse the caller's tree exactly as handed over (BVH.hpp:18-31 nodes over the BVH-order prims)
-			const std::string why = mirt_host::build_records(nodes, n_nodes, bvh_prims, n_spheres, recs, &depth);
+			std::vector<mirt_bvh_node> own(nodes, nodes + n_nodes);
+			mirt_host::split_multi_prim_leaves(own);                         // the kernels know one-prim leaves only
+			const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth);
 			if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str());
 		} else {
 			// default: GPU-internal SAH tree over the same BVH-order prims (hit.primID keeps its meaning; results are identical)
@@ -555,16 +570,16 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
 	s.half_boxes = half ? 1u : 0u;
 	s.stack16 = (half && n_recs <= 65535) ? 1u : 0u;
-	s.multi_prim_leaves = 0;
-	if (c->policy.reference_tree) for (uint32_t i = 0; i < n_nodes; i++) if (nodes[i].prim_count > 1) { s.multi_prim_leaves = 1; break; }
 	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half, s.stack16 != 0);
 	if (static_cast<uint64_t>(n_recs) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u <= budget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
 	else { s.lds_recs = std::min<uint32_t>(n_recs, budget / rec_bytes); s.lds_spheres = 0; }
 	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
 	{
 		const int lds_max = static_cast<int>(kLdsPerCu);
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 	}
 	for (int k = 0; k < 3; k++) s.ambient[k] = ambient_color[k];
 	s.hdri_w = static_cast<int32_t>(hdri_w); s.hdri_h = static_cast<int32_t>(hdri_h);
@@ -708,6 +723,8 @@ int mirt_accumulator_device(mirt_ctx* c, void** ptr, size_t* bytes) {
 	if (!c || !ptr || !bytes) return MIRT_ERR_ARG;
 	size_t n = 0; mirt_accumulator_floats(c, &n);
 	{ const int fr = flush_deferred(c); if (fr) return fr; }
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, sync_all(c));                                                           // the caller reads the slab on a stream of its own (RCCL gather): everything enqueued here has landed
 	*ptr = c->accumulator.ptr; *bytes = n * sizeof(float);
 	return MIRT_OK;
 }
@@ -817,9 +834,9 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter, fat count closest, fat count shadow }
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	const FatList fc{ cnt.as<uint32_t>() + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cnt.as<uint32_t>() + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
-	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
+	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
 	                   ShadowBuf{}, ShadowSink{}, cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
@@ -850,9 +867,9 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	const FatList fc{ cn + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cn + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
 	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
-	hipLaunchKernelGGL(k_trace<false>, dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), cn, cn + 1,
+	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), cn, cn + 1,
 	                   sh, sink, cn + 2, cn + 3, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL(k_trace_fat<false>, dim3(64), dim3(1024), 0, c->stream, sc, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
@@ -882,7 +899,7 @@ int mirt_debug_info(mirt_ctx* c, uint32_t out[8]) {
 	if (!c || !out) return MIRT_ERR_ARG;
 	const SceneDev& s = c->scene;
 	uint32_t per_cu = kLdsPerCu / std::max<uint32_t>(trace_lds(c), 1u);
-	per_cu = std::min<uint32_t>(std::max<uint32_t>(per_cu, 1u), 2u);
+	per_cu = std::min<uint32_t>(std::max<uint32_t>(per_cu, 1u), c->tune_trace_wgs);
 	out[0] = s.n_recs; out[1] = s.lds_recs; out[2] = s.lds_spheres; out[3] = c->bvh_depth; out[4] = s.half_boxes;
 	out[5] = trace_lds(c); out[6] = per_cu; out[7] = static_cast<uint32_t>(c->n_cu);
 	return MIRT_OK;

@@ -3,7 +3,9 @@
 // (Resize -> [Accumulate, Render] per frame) through mirt_host.hpp, and writes the resolved frame as a PFM
 // (the reference's F5 screenshot is stbi_write_hdr of the same RGBA buffer, flipped vertically: Image.cpp:71-74).
 //
-//   mirt_headless --scene default9|furnace|synthetic:N [--size WxH] [--spp N] [--bounces B] [--buckets K] [--brute] [--out f.pfm]
+//   mirt_headless --scene default9|furnace|bvh_test|synthetic:N [--size WxH] [--spp N | --frames N] [--bounces B] [--buckets K] [--brute] [--out f.pfm]
+// --frames N is the UI loop itself (Application.cpp:373-380): N frames of { Accumulate(); Render(); }; the report lists the frames on
+// which Render() produced output (every `buckets`-th, Renderer.hpp:437) and a hash of the last frame shown.
 #include "mirt_host.hpp"
 
 #include <chrono>
@@ -70,6 +72,32 @@ static void scene_synthetic(Scene& sc, uint32_t n, float ambient) {
 	sc.sky.ambient_color[0] = sc.sky.ambient_color[1] = sc.sky.ambient_color[2] = ambient;
 }
 
+// Scenes::BVH_test, Application.cpp:102-122, fixed version (see scene.py bvh_test(): the shipped scene has an empty material list and
+// a std::mt19937 whose distributions differ between standard libraries): eight Lambertian materials, the reference's PCG seeded with
+// hash_u32 of the low 32 bits of the shipped seed, draws per sphere in the shipped order radius, x, y, z, material.
+static void scene_bvh_test(Scene& sc) {
+	uint32_t st = hash_u32(0x04d15a07u);
+	sc.material.assign(8, Material{});
+	for (int m = 0; m < 8; m++) for (int c = 0; c < 3; c++) sc.material[m].albedo[c] = 0.2f + 0.7f * next_unit(st);
+	sc.geometry.clear();
+	for (int i = 0; i < 255; i++) {
+		const float r = 0.3f + 19.7f * next_unit(st);
+		const float x = -100.0f + 200.0f * next_unit(st);
+		const float y = 100.0f * next_unit(st);
+		const float z = -100.0f + 200.0f * next_unit(st);
+		const uint32_t m = static_cast<uint32_t>(next_unit(st) * 8.0f);
+		sc.geometry.push_back(make_sphere(x, y, z, r * r, static_cast<int32_t>(m < 7u ? m : 7u)));
+	}
+	sc.camera = Camera{ vec3{ 0, 60, 300 }, vec3{ 0, 0, -1 } };
+	sc.sky.ambient_color[0] = sc.sky.ambient_color[1] = sc.sky.ambient_color[2] = 1.0f;
+}
+
+static uint64_t fnv1a(const std::vector<float>& v) {
+	uint64_t hsh = 1469598103934665603ull;
+	for (float f : v) { uint32_t u; std::memcpy(&u, &f, 4); for (int b = 0; b < 4; b++) { hsh ^= (u >> (8 * b)) & 0xffu; hsh *= 1099511628211ull; } }
+	return hsh;
+}
+
 static bool write_pfm(const std::string& path, const std::vector<float>& rgba, uint32_t w, uint32_t h) {
 	FILE* f = std::fopen(path.c_str(), "wb");
 	if (!f) return false;
@@ -93,7 +121,7 @@ int main(int argc, char** argv) {
 		auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
 		if (a == "--scene") scene_name = next();
 		else if (a == "--size") { if (std::sscanf(next(), "%ux%u", &w, &h) != 2) return 2; }
-		else if (a == "--spp") spp = static_cast<uint32_t>(std::atoi(next()));
+		else if (a == "--spp" || a == "--frames") spp = static_cast<uint32_t>(std::atoi(next()));
 		else if (a == "--bounces") policy.max_bounces = static_cast<uint32_t>(std::atoi(next()));
 		else if (a == "--buckets") policy.buckets = static_cast<uint32_t>(std::atoi(next()));
 		else if (a == "--ambient") ambient = static_cast<float>(std::atof(next()));
@@ -105,6 +133,7 @@ int main(int argc, char** argv) {
 		Scene scene;
 		if (scene_name == "default9") scene_default9(scene);
 		else if (scene_name == "furnace") scene_furnace(scene);
+		else if (scene_name == "bvh_test") scene_bvh_test(scene);
 		else if (scene_name.rfind("synthetic:", 0) == 0) { n = static_cast<uint32_t>(std::atoi(scene_name.c_str() + 10)); if (n < 2) return 2; scene_synthetic(scene, n, ambient); }
 		else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
 		scene.RebuildAcceleration();                                   // Application.cpp:233-234
@@ -119,9 +148,10 @@ int main(int argc, char** argv) {
 
 		const auto t0 = std::chrono::steady_clock::now();
 		bool have_frame = false;
+		std::string frames_due;                                        // 1-based frame numbers on which Render() produced output
 		for (uint32_t frame = 0; frame < spp; frame++) {               // one UIRender per frame: Accumulate(); Render();  (Application.cpp:379-380)
 			renderer.Accumulate();
-			have_frame = renderer.Render() || have_frame;
+			if (renderer.Render()) { have_frame = true; frames_due += (frames_due.empty() ? "" : ", ") + std::to_string(frame + 1); }
 		}
 		const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		const mirt_counters c = renderer.counters();
@@ -130,15 +160,15 @@ int main(int argc, char** argv) {
 		size_t nf = 0; mirt_accumulator_floats(renderer.handle(), &nf);
 		std::vector<float> acc(nf);
 		mirt_read_accumulator(renderer.handle(), acc.data());
-		uint64_t hsh = 1469598103934665603ull;
-		for (float v : acc) { uint32_t u; std::memcpy(&u, &v, 4); for (int b = 0; b < 4; b++) { hsh ^= (u >> (8 * b)) & 0xffu; hsh *= 1099511628211ull; } }
+		const uint64_t hsh = fnv1a(acc);
+		const uint64_t frame_hsh = have_frame ? fnv1a(renderer.GetFrame()) : 0ull;
 
 		std::printf("{\"scene\": \"%s\", \"spheres\": %zu, \"nodes\": %zu, \"lights\": %zu, \"width\": %u, \"height\": %u, \"accumulations\": %u, "
 		            "\"rays\": %llu, \"shadow_rays\": %llu, \"terminated\": %llu, \"dropped\": %llu, \"seconds\": %.6f, \"mray_per_s\": %.3f, "
-		            "\"accumulator_fnv1a\": \"%016llx\", \"frame_ready\": %s}\n",
+		            "\"accumulator_fnv1a\": \"%016llx\", \"frame_ready\": %s, \"frames_due\": [%s], \"last_frame_fnv1a\": \"%016llx\"}\n",
 		            scene_name.c_str(), scene.geometry.size(), scene.acceleration_structure.nodes.size(), scene.lighting_acceleration.prims.size(), w, h,
 		            renderer.accumulations(), (unsigned long long)c.rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.terminated,
-		            (unsigned long long)c.dropped, sec, c.rays / sec / 1e6, (unsigned long long)hsh, have_frame ? "true" : "false");
+		            (unsigned long long)c.dropped, sec, c.rays / sec / 1e6, (unsigned long long)hsh, have_frame ? "true" : "false", frames_due.c_str(), (unsigned long long)frame_hsh);
 		if (!out.empty() && have_frame && !write_pfm(out, renderer.GetFrame(), w, h)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "mirt_headless: %s\n", e.what());

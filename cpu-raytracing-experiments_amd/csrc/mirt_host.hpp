@@ -126,7 +126,11 @@ public:
 		if (mirt_create(device, &ctx_) != MIRT_OK) throw std::runtime_error(std::string("mirt_create: ") + mirt_last_error(nullptr));
 		mirt_policy p{};
 		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh; p.reference_tree = policy.reference_tree; p.gpu_build = policy.gpu_build;
-		check(mirt_set_policy(ctx_, &p), "mirt_set_policy");
+		if (mirt_set_policy(ctx_, &p) < 0) {                                  // no destructor runs for a constructor that throws: release the context here
+			const std::string why = std::string("mirt_set_policy: ") + mirt_last_error(ctx_);
+			mirt_destroy(ctx_); ctx_ = nullptr;
+			throw std::runtime_error(why);
+		}
 	}
 	~Renderer() { if (ctx_) mirt_destroy(ctx_); }
 	Renderer(const Renderer&) = delete;

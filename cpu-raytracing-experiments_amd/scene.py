@@ -173,6 +173,41 @@ def white_furnace() -> Scene:
                  cam, np.ones(3, dtype=f32), name="white_furnace")
 
 
+def pcg_stream(state: int):
+    """Generator of successive pcg_generate outputs (Random.hpp:20-24) as Python ints."""
+    s = state & 0xFFFFFFFF
+    while True:
+        v = s
+        s = (s * 747796405 + 2891336453) & 0xFFFFFFFF
+        v = (((v >> ((v >> 28) + 4)) ^ v) * 277803737) & 0xFFFFFFFF
+        yield (v >> 22) ^ v
+
+
+def bvh_test() -> Scene:
+    """Scenes::BVH_test, Application.cpp:102-122, in a FIXED version: 255 random spheres (radius 0.3..20, x/z in +-100, y in 0..100)
+    under a constant-1 sky, camera {0,60,300} looking down -z.  As shipped the scene cannot run: its material list is empty
+    (`mat_dist(0, size-1)` with size 0) and std::mt19937 + std::uniform_*_distribution differ between standard libraries.
+    Fixed here (and identically in csrc/mirt_headless.cpp): eight Lambertian materials, and the reference's own PCG
+    (Random.hpp:20-34) seeded with hash_u32 of the low 32 bits of the shipped seed; draws per sphere in the shipped order:
+    radius, x, y, z, material."""
+    g = pcg_stream(hash_u32(0x04D15A07))
+    unit = lambda: f32(next(g)) * f32(2.0 ** -32)       # noqa: E731  rand_unit_float
+    mats = np.zeros(8, dtype=MATERIAL)
+    for m in range(8):
+        for c in range(3):
+            mats["albedo"][m, c] = f32(0.2) + f32(0.7) * unit()
+    geo = np.zeros(255, dtype=SPHERE)
+    for i in range(255):
+        r = f32(0.3) + f32(19.7) * unit()
+        x = f32(-100.0) + f32(200.0) * unit()
+        y = f32(100.0) * unit()
+        z = f32(-100.0) + f32(200.0) * unit()
+        m = min(7, int(np.uint32(unit() * f32(8.0))))    # rand_bounded_int(state, 8)
+        geo[i] = _sphere((x, y, z), r * r, m)
+    cam = Camera(eye=(0.0, 60.0, 300.0), direction=(0.0, 0.0, -1.0), focal_length=50.0, exposure=1.0)
+    return Scene(geo, mats, cam, np.ones(3, dtype=f32), name="bvh_test")
+
+
 def synthetic(n: int, ambient: float = 0.0, scene_seed: int = 1) -> Scene:
     """S(n) of SURVEY.md §8d: ground sphere + n-1 random spheres at constant density, 16 Lambertian
     materials + one emissive material on every 64th sphere; generator = the reference's own PCG."""

@@ -172,7 +172,8 @@ int mirt_get_accumulations(const mirt_ctx* ctx, uint32_t* accumulations);
 /* `accumulator` member, Renderer.hpp:43-46: [local tile][bucket][r,g,b][256] f32. */
 int mirt_accumulator_floats(const mirt_ctx* ctx, size_t* n_floats);
 int mirt_read_accumulator(mirt_ctx* ctx, float* host_dst);
-/* Device address of that slab (for an RCCL gather by the caller); valid until the next resize / tile-range call. */
+/* Device address of that slab (for an RCCL gather by the caller); valid until the next resize / tile-range call.
+ * Launches anything deferred and waits for the GPU first, so the slab is complete whatever stream the caller reads it on. */
 int mirt_accumulator_device(mirt_ctx* ctx, void** device_ptr, size_t* bytes);
 /* Checkpoint/resume and post-gather resolve: overwrite the slab (src on host or device) and set `accumulations`. */
 int mirt_load_accumulator(mirt_ctx* ctx, const float* src, int src_is_device, uint32_t accumulations);

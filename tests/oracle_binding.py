@@ -18,6 +18,12 @@ _lib = None
 TRAV_BRUTE, TRAV_STREAM_BVH, TRAV_PER_RAY_BVH = 0, 1, 2
 
 
+def set_exact_tail(on):
+    """Brute-force mode only: the last `rays % 8` rays of each 256-ray stream take the reference's unfused scalar tail
+    (BVH.hpp:270-286) instead of the FMA form every other ray uses.  Process-wide switch."""
+    load().orc_set_exact_tail(int(bool(on)))
+
+
 def build():
     subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     return LIB
@@ -41,6 +47,8 @@ def load():
     lib.orc_get_lights.argtypes = [vp, vp]
     lib.orc_set_camera.argtypes = [vp, vp, vp, f, f, f, f]
     lib.orc_config.argtypes = [vp, u32, u32, u32, u32, i32, i32, i32]
+    lib.orc_config_tiles.argtypes = [vp, u32, u32, u32, u32, i32, i32, i32, vp, u32]
+    lib.orc_set_exact_tail.argtypes = [i32]
     lib.orc_reset.argtypes = [vp]
     lib.orc_accumulate.argtypes = [vp, u32]
     lib.orc_accumulations.argtypes = [vp]; lib.orc_accumulations.restype = u32
@@ -139,11 +147,17 @@ class Oracle:
         self.lib.orc_get_lights(self.h, _p(out))
         return out[:n]
 
-    def Resize(self, w, h):
+    def Resize(self, w, h, tiles=None):
+        """Renderer::Resize.  `tiles`: render only these LaunchIndices of the w x h image (spot checks at full BASELINE sizes);
+        accumulator() then holds one slab per listed tile, in list order, and there is no frame to Render()."""
         self.width, self.height = w, h
         self.scene.camera.resize(w, h)
         self.update_camera()
-        rc = self.lib.orc_config(self.h, w, h, self.max_bounces, self.buckets, int(self.mis), self.trav_mode, self.threads)
+        if tiles is None:
+            rc = self.lib.orc_config(self.h, w, h, self.max_bounces, self.buckets, int(self.mis), self.trav_mode, self.threads)
+        else:
+            t = np.ascontiguousarray(tiles, dtype=np.uint32)
+            rc = self.lib.orc_config_tiles(self.h, w, h, self.max_bounces, self.buckets, int(self.mis), self.trav_mode, self.threads, _p(t), len(t))
         assert rc == 0
 
     def ResetAccumulator(self):

@@ -192,6 +192,7 @@ def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
         t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(w, h); t.Accumulate(spp)
         ct = t.counters()
         assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
+        assert cg["shadow_nodes"] == ct["shadow_nodes"] and cg["shadow_spheres"] == ct["shadow_spheres"]
     r.close()
 
 
@@ -212,6 +213,7 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     t = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(128, 128); t.Accumulate(5)
     cg, ct = r.counters(), t.counters()
     assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
+    assert cg["shadow_nodes"] == ct["shadow_nodes"] and cg["shadow_spheres"] == ct["shadow_spheres"]
     if not reference_tree:
         ref = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, count_traffic=True); ref.Resize(128, 128); ref.Accumulate(5)
         assert cg["nodes"] < 0.6 * ref.counters()["nodes"]          # the internal SAH tree roughly halves the box tests
@@ -279,8 +281,7 @@ def test_caller_tree_with_multi_prim_leaves(mirt):
         r.Resize(96, 96); r.Accumulate(5)
         assert r.debug_info()["half_boxes"] == int(allow_half)
         assert_same(r.accumulator(), o.accumulator(), f"multi-prim leaves, half={allow_half}")
-        c = r.counters()
-        assert c["spheres"] > c["rays"]                      # several prims per visited leaf
+        assert r.debug_info()["records"] == len(prims) - 1   # every k-prim leaf became a subtree of k one-prim leaves (bvh_layout.hpp)
         r.close()
 
 
@@ -521,6 +522,17 @@ def test_edge_cases_and_errors(mirt):
     bad = mirt.scene.default9(); bad.geometry["material_ID"][3] = 99
     with pytest.raises(mirt.MirtError):
         mirt.Renderer(bad)
+    # a caller's tree whose inner nodes share children (node 1 -> {2,3}, node 2 -> {3,4}) is refused, not walked
+    r = mirt.Renderer(mirt.scene.default9(), reference_tree=True, use_bvh=True)
+    nodes = r.nodes.copy()
+    bad_nodes = np.zeros(7, dtype=mirt.scene.NODE)
+    bad_nodes["min_bound"] = -10.0; bad_nodes["max_bound"] = 10.0
+    bad_nodes["first_id"] = [1, 3, 3, 0, 1, 2, 3]; bad_nodes["prim_count"] = [0, 0, 0, 1, 1, 1, 1]
+    bad_nodes["first_id"][2] = 4                                             # node 1 -> {3,4}, node 2 -> {4,5}: node 4 has two parents
+    with pytest.raises(mirt.MirtError, match="more than one parent"):
+        r.UpdateScene(nodes=bad_nodes)
+    r.UpdateScene(nodes=nodes)                                               # the context stays usable
+    r.close()
     for field, value in (("position", np.nan), ("position", np.inf), ("radius_sq", -1.0), ("radius_sq", np.nan)):
         bad = mirt.scene.default9()
         if field == "position": bad.geometry["position"][2, 1] = value
@@ -529,34 +541,53 @@ def test_edge_cases_and_errors(mirt):
             mirt.Renderer(bad)
 
 
-def test_cpp_host_matches_python_host(mirt, tmp_path):
-    """The C++ host mirror (csrc/mirt_host.hpp + mirt_headless, reference call protocol: Accumulate();Render() per frame)
-    must produce the same accumulator as the Python host — both only marshal the scene into the same C-ABI."""
+def _fnv1a(acc):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(acc, dtype=np.float32).view(np.uint8).ravel().tolist():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def test_cpp_host_matches_golden_and_oracle(mirt, tmp_path):
+    """The C++ host mirror (csrc/mirt_host.hpp + mirt_headless, reference call protocol: Accumulate(); Render() per frame):
+    its accumulator (FNV-1a of the raw words) and its PFM frame must equal the committed golden vector / the live oracle."""
     import json
     import subprocess
     exe = os.path.join(mirt.CSRC, "mirt_headless")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", mirt.CSRC, "mirt_headless"], check=True)
 
-    def fnv(acc):
-        h = 1469598103934665603
-        for b in np.ascontiguousarray(acc, dtype=np.float32).view(np.uint8).ravel().tolist():
-            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-        return f"{h:016x}"
-
-    for args, sc, w, hgt, spp, mb in [(["--scene", "default9"], mirt.scene.default9(), 64, 48, 10, 16),
-                                      (["--scene", "synthetic:1000", "--ambient", "0.5", "--bounces", "5"], mirt.scene.synthetic(1000, ambient=0.5), 64, 32, 5, 5)]:
+    g = np.load(os.path.join(GOLDEN, "default9_64x64_10spp_b16.npz"))
+    o = ob.Oracle(mirt.scene.synthetic(1000, ambient=0.5), max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(64, 32); o.Accumulate(5)
+    ob9 = ob.Oracle(mirt.scene.bvh_test(), max_bounces=16, trav_mode=ob.TRAV_BRUTE); ob9.Resize(64, 48); ob9.Accumulate(10)
+    cases = [(["--scene", "default9"], 64, 64, 10, g["accumulator"], g["frame"], int(g["rays"])),
+             (["--scene", "synthetic:1000", "--ambient", "0.5", "--bounces", "5"], 64, 32, 5, o.accumulator(), o.Render(), o.counters()["rays"]),
+             (["--scene", "bvh_test"], 64, 48, 10, ob9.accumulator(), ob9.Render(), ob9.counters()["rays"])]
+    for args, w, hgt, spp, want_acc, want_frame, want_rays in cases:
         pfm = str(tmp_path / "frame.pfm")
         out = subprocess.run([exe, *args, "--size", f"{w}x{hgt}", "--spp", str(spp), "--out", pfm], check=True, capture_output=True, text=True).stdout
         rep = json.loads(out)
-        r = mirt.Renderer(sc, max_bounces=mb, use_bvh=True); r.Resize(w, hgt); r.Accumulate(spp); assert r.Render()
-        assert rep["accumulations"] == spp and rep["rays"] == r.counters()["rays"] and rep["frame_ready"]
-        assert rep["accumulator_fnv1a"] == fnv(r.accumulator())
+        assert rep["accumulations"] == spp and rep["rays"] == want_rays and rep["frame_ready"], args
+        assert rep["accumulator_fnv1a"] == _fnv1a(want_acc), args
         raw = open(pfm, "rb").read()
         assert raw.startswith(b"PF\n") and len(raw) == len(f"PF\n{w} {hgt}\n-1.0\n") + w * hgt * 12
         img = np.frombuffer(raw[-w * hgt * 12:], dtype="<f4").reshape(hgt, w, 3)
-        assert np.array_equal(img, r.GetFrame()[..., :3])
-        r.close()
+        assert np.array_equal(img.view(np.uint32), np.ascontiguousarray(want_frame[..., :3]).view(np.uint32)), args
+
+
+def test_cpp_host_frame_loop(mirt):
+    """--frames N: the reference's UI loop (Application.cpp:373-380) — every frame Accumulate(); Render(); — reported per frame:
+    a frame is due on every 5th call (Renderer.hpp:437) and the last due frame equals the oracle's."""
+    import json
+    import subprocess
+    exe = os.path.join(mirt.CSRC, "mirt_headless")
+    out = subprocess.run([exe, "--scene", "default9", "--size", "64x48", "--frames", "12"], check=True, capture_output=True, text=True).stdout
+    rep = json.loads(out)
+    assert rep["accumulations"] == 12 and rep["frames_due"] == [5, 10] and rep["frame_ready"]
+    o = ob.Oracle(mirt.scene.default9(), max_bounces=16, trav_mode=ob.TRAV_BRUTE); o.Resize(64, 48)
+    o.Accumulate(10); frame10 = o.Render(); o.Accumulate(2)
+    assert rep["accumulator_fnv1a"] == _fnv1a(o.accumulator())
+    assert rep["last_frame_fnv1a"] == _fnv1a(frame10)
 
 
 @pytest.mark.parametrize("n,w,h,spp,mb", [(10000, 256, 192, 5, 9), (100000, 192, 128, 5, 9)])
@@ -573,6 +604,66 @@ def test_large_scenes_bvh_equals_brute_force(mirt, n, w, h, spp, mb):
         assert_same(r.accumulator(), want, f"S({n}) BVH (reference_tree={reference_tree}) vs brute force")
         assert r.counters()["rays"] == wc["rays"] and r.counters()["terminated"] == wc["terminated"]
         r.close()
+
+
+@pytest.mark.parametrize("name,n,mb,buckets,w,h,spp", [("cfg3", 10000, 9, 5, 256, 192, 5), ("cfg4", 100000, 9, 5, 128, 96, 5), ("cfg5", 100000, 17, 16, 96, 64, 16)])
+def test_baseline_scenes_and_policies_vs_brute_force_oracle(mirt, name, n, mb, buckets, w, h, spp):
+    """BASELINE cfg3 / cfg4 / cfg5: their own scene S(n) and their own policy (bounce iterations, buckets, MIS), at a resolution
+    the oracle's brute-force loops (the reference as shipped, BVH.hpp:312 / :365) finish in seconds on the host threads.
+    The shipped GPU pipeline must reproduce the oracle's accumulators and frame bit for bit."""
+    sc = mirt.scene.synthetic(n)
+    o = ob.Oracle(sc, max_bounces=mb, buckets=buckets, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+    r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, use_bvh=True); r.Resize(w, h); r.Accumulate(spp)
+    assert_same(r.accumulator(), o.accumulator(), f"{name} scene and policy, {w}x{h}x{spp}: HIP BVH pipeline vs brute-force oracle")
+    if spp % buckets == 0:
+        assert r.Render(); assert_same(r.GetFrame(), o.Render(), f"{name} frame")
+    cg, co = r.counters(), o.counters()
+    assert cg["rays"] == co["rays"] and cg["shadow_rays"] == co["shadow_rays"] and cg["terminated"] == co["terminated"]
+    assert cg["terminated"] + cg["dropped"] == spp * (w // 16) * (h // 16) * 256
+    r.close()
+
+
+@pytest.mark.parametrize("name,n_tiles,spp", [("cfg3", 64, 5), ("cfg4", 40, 5), ("cfg5", 16, 16)])
+def test_full_size_spot_checks_vs_oracle(mirt, name, n_tiles, spp):
+    """BASELINE cfg3 / cfg4 / cfg5 at their FULL image size (1920x1088, 4096x4096): the shipped pipeline (batches, streams,
+    contribution buffers) renders the whole image; the oracle renders a spread of its 16x16 tiles with the brute-force loops
+    (every random draw depends only on the global LaunchIndex, pixel and accumulation: Renderer.hpp:107,117).  Those tiles'
+    accumulator slabs must agree bit for bit, every path of the image must be accounted for."""
+    cfg = mirt.scene.CONFIGS[name]
+    w, h, mb, buckets = cfg["width"], cfg["height"], cfg["max_bounces"], cfg["buckets"]
+    sc = mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])
+    h_tiles, v_tiles = w // 16, h // 16
+    rng = np.random.default_rng(11)
+    tiles = np.unique(np.concatenate([[0, h_tiles - 1, (v_tiles - 1) * h_tiles, v_tiles * h_tiles - 1, (v_tiles // 2) * h_tiles + h_tiles // 2],
+                                      rng.integers(0, h_tiles * v_tiles, n_tiles - 5)])).astype(np.uint32)
+    r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, use_bvh=True); r.Resize(w, h); r.Accumulate(spp)
+    c = r.counters()
+    assert c["terminated"] + c["dropped"] == spp * h_tiles * v_tiles * 256
+    got = r.accumulator()[tiles]
+    r.close()
+    o = ob.Oracle(sc, max_bounces=mb, buckets=buckets, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h, tiles=tiles); o.Accumulate(spp)
+    assert_same(got, o.accumulator(), f"{name} full size {w}x{h}: {len(tiles)} tiles vs brute-force oracle")
+    assert got.any()
+
+
+@pytest.mark.parametrize("name,spp", [("cfg3", 5), ("cfg4", 2)])
+def test_full_size_bvh_equals_brute_force(mirt, name, spp):
+    """BASELINE cfg3 / cfg4 at full size: the BVH pipeline and the brute-force path (the reference as shipped) agree on every word
+    of the whole accumulator, and every path is accounted for (size-independent property; the oracle covers a spread of tiles
+    of the same images in test_full_size_spot_checks_vs_oracle)."""
+    cfg = mirt.scene.CONFIGS[name]
+    w, h, mb = cfg["width"], cfg["height"], cfg["max_bounces"]
+    sc = mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])
+    fast = mirt.Renderer(sc, max_bounces=mb, use_bvh=True); fast.Resize(w, h); fast.AccumulateAsync(spp)
+    slow = mirt.Renderer(sc, max_bounces=mb, use_bvh=False, streams=1); slow.Resize(w, h); slow.Accumulate(spp)
+    fast.Synchronize()
+    cf, cs = fast.counters(), slow.counters()
+    assert cf["rays"] == cs["rays"] and cf["shadow_rays"] == cs["shadow_rays"]
+    assert cf["terminated"] + cf["dropped"] == spp * (w // 16) * (h // 16) * 256 == cs["terminated"] + cs["dropped"]
+    a, b = fast.accumulator(), slow.accumulator()
+    fast.close(); slow.close()
+    assert_same(a, b, f"{name} full size: BVH pipeline vs brute force")
+    assert np.isfinite(a).all() and (a >= 0).all()
 
 
 def test_cfg5_policy_16_buckets_17_bounces(mirt):
@@ -608,14 +699,14 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     env = dict(os.environ, MIRT_BENCH_SHARE_GPU="1", MIRT_BENCH_BACKEND="gloo")
     port = 29700 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "5", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "cfg2", "--spp", "5", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["image"] == "2048x1024" and d["gather_ms"] is not None
-    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["rays_per_step"] > 2 * 9e6
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["image"] == "1024x1024" and d["gather_ms"] is not None
+    assert d["value"] > 0 and d["roofline"]["bound"] == "valu" and d["roofline"]["hbm"]["frac"] > 0 and d["rays_per_step"] > 9e6
 
 
 def test_cfg2_full_size_properties(mirt):
