@@ -1007,7 +1007,11 @@ static void accumulate_tile(const Oracle& o, uint32_t LaunchIndex, size_t slab, 
 		                                     ray_stream.RayID, ray_stream.hit.matID, sort_buffer);   // :235-241
 		const size_t hit_count = active_rays - miss_count;
 
-		if (MIS) {                                                               // :247-315
+		// Twin mode only: hits of the LAST bounce are never accumulated (Q5: Renderer.hpp:358,424-425 drops them), so the product
+		// emits no NEE rays for them; the reference (modes 0, 1) still traces those shadow rays.  Skipping them changes no result,
+		// only the shadow-ray / box / sphere counters, which in mode 2 mirror the HIP kernels'.
+		const bool skip_dropped_nee = o.trav_mode == 2 && !(bounce < o.max_bounces - 1);
+		if (MIS && !skip_dropped_nee) {                                          // :247-315
 			size_t shadow_index = 0;
 			ShadowStream& sh = ray_stream.shadow_rays;
 			for (size_t i = 0; i < hit_count; i++) {

@@ -2,7 +2,7 @@
 # Edit-measure loop on the GPU box: GPU tests, the default bench line (cfg4, with its rocprofv3 --pmc child passes), then short
 # A/B runs of launch-shape knobs.  A step that times out ends the cycle (no further GPU work after a hang).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-step() { name=$1; shift; timeout -k 10 "$@"; rc=$?; echo "[$name] rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] timed out: stopping"; exit 1; fi; return 0; }
+step() { name=$1; shift; timeout -k 10 "$@"; rc=$?; echo "[$name] rc=$rc" >&2; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] timed out: stopping" >&2; exit 1; fi; return 0; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   step pytest 1100 python -m pytest tests -m gpu -q -x --durations=8 > gpurun_out/pytest_gpu.log 2>&1; tail -15 gpurun_out/pytest_gpu.log
 fi

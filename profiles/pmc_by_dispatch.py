@@ -20,5 +20,7 @@ for (i, k), d in sorted(r1.items()):
     if pat not in k: continue
     e = r2.get((i, k), {})
     util = d["SQ_THREAD_CYCLES_VALU"] / max(d["SQ_ACTIVE_INST_VALU"] * 64, 1)
-    print(i, k[:26].ljust(26), "us %7.1f" % d["us"], "VALU %.3g SALU %.3g LDS %.3g VMEM %.3g" % (d["SQ_INSTS_VALU"], d["SQ_INSTS_SALU"], e.get("SQ_INSTS_LDS", 0), e.get("SQ_INSTS_VMEM", 0)),
-          "lane-util %.2f" % util, "wait %.2f" % (d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]), "lds-conflict %.2f" % (e.get("SQ_LDS_BANK_CONFLICT", 0) / max(e.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
+    print(i, k[:30].ljust(30), "us %7.1f" % d["us"], "VALU %.3g SALU %.3g LDS %.3g VMEM %.3g" % (d["SQ_INSTS_VALU"], d["SQ_INSTS_SALU"], e.get("SQ_INSTS_LDS", 0), e.get("SQ_INSTS_VMEM", 0)),
+          "lane-util %.2f" % util, "wait %.2f" % (d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]), "issue-wait %.2f" % (e.get("SQ_WAIT_INST_ANY", 0) / max(d["SQ_WAVE_CYCLES"], 1)),
+          "active %.2f" % (e.get("SQ_ACTIVE_INST_ANY", 0) / max(d["SQ_WAVE_CYCLES"], 1)), "lds-conflict %.2f" % (e.get("SQ_LDS_BANK_CONFLICT", 0) / max(e.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
+          "valu-busy %.2f" % (d["SQ_ACTIVE_INST_VALU"] * 4 / max(d["SQ_BUSY_CYCLES"], 1)))

@@ -192,7 +192,7 @@ def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
         t = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(w, h); t.Accumulate(spp)
         ct = t.counters()
         assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
-        assert cg["shadow_nodes"] == ct["shadow_nodes"] and cg["shadow_spheres"] == ct["shadow_spheres"]
+        assert cg["shadow_rays"] == ct["shadow_rays"] and cg["shadow_nodes"] == ct["shadow_nodes"] and cg["shadow_spheres"] == ct["shadow_spheres"]
     r.close()
 
 
@@ -618,7 +618,8 @@ def test_baseline_scenes_and_policies_vs_brute_force_oracle(mirt, name, n, mb, b
     if spp % buckets == 0:
         assert r.Render(); assert_same(r.GetFrame(), o.Render(), f"{name} frame")
     cg, co = r.counters(), o.counters()
-    assert cg["rays"] == co["rays"] and cg["shadow_rays"] == co["shadow_rays"] and cg["terminated"] == co["terminated"]
+    assert cg["rays"] == co["rays"] and cg["terminated"] == co["terminated"]
+    assert cg["shadow_rays"] <= co["shadow_rays"]           # the reference also traces NEE rays of last-bounce hits, whose paths it then drops (Q5)
     assert cg["terminated"] + cg["dropped"] == spp * (w // 16) * (h // 16) * 256
     r.close()
 

@@ -114,7 +114,11 @@ def test_oracle_matches_golden(mirt, name, mode):
     else:
         assert img is None                                # accumulations % buckets != 0 (Renderer.hpp:437)
     c = o.counters()
-    assert c["rays"] == int(g["rays"]) and c["shadow_rays"] == int(g["shadow_rays"]) and c["terminated"] == int(g["terminated"])
+    assert c["rays"] == int(g["rays"]) and c["terminated"] == int(g["terminated"])
+    if mode == ob.TRAV_BRUTE:
+        assert c["shadow_rays"] == int(g["shadow_rays"])
+    else:                                                 # the twin, like the product, emits no NEE rays for last-bounce hits (dropped anyway, Q5)
+        assert c["shadow_rays"] <= int(g["shadow_rays"])
 
 
 def test_accumulation_is_incremental_and_thread_independent(mirt):
@@ -180,7 +184,8 @@ def test_robust_bvh_equals_brute_force(mirt):
         twin = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); twin.Resize(w, h); twin.Accumulate(spp)
         assert np.array_equal(bits(ref.accumulator()), bits(twin.accumulator()))
         cr, ct = ref.counters(), twin.counters()
-        assert cr["rays"] == ct["rays"] and cr["shadow_rays"] == ct["shadow_rays"] and cr["terminated"] == ct["terminated"]
+        assert cr["rays"] == ct["rays"] and cr["terminated"] == ct["terminated"]
+        assert 0 < ct["shadow_rays"] <= cr["shadow_rays"]   # the twin, like the product, emits no NEE rays for last-bounce hits (their paths are dropped, Q5)
         assert ct["spheres"] < cr["spheres"]
 
 
