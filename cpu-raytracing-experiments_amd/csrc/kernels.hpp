@@ -108,12 +108,62 @@ MIRT_DI void wave_sum(uint32_t v, unsigned long long* counter) {
 	if (lane_id() == 0 && v) atomicAdd(counter, static_cast<unsigned long long>(v));
 }
 
-// Two-stream compaction for a whole workgroup: wave64 ballots give per-wave counts, one lane per stream adds the
-// workgroup total to the stream counter (ONE global atomic per stream per `blockDim.x` rays — same-address returning
-// atomics serialise at ~11 ns each, which dominated the first version of k_shade), and every lane gets
-// base + (counts of earlier waves) + (rank inside its wave).  Must be called by all threads of the block, converged.
-// `scratch` = 2*2*16+2*2 words of LDS, double-buffered on `parity` so consecutive calls need no third barrier.
-MIRT_DI void block_append2(bool flag_a, bool flag_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t* scratch, uint32_t parity,
+// ---- ray queues -----------------------------------------------------------------------------------------------
+// A ray queue (the rays of one bounce, or its NEE shadow rays) is kSegs dense SEGMENTS of the stream planes at fixed offsets:
+// segment k holds slots [k * seg_cap, k * seg_cap + n[k]).  Producers (k_shade's compaction) append block-iteration t to
+// segment t % kSegs, so the one returning atomicAdd per workgroup and 512 rays is spread over kSegs counters, each on a
+// cache line of its own: same-address returning atomics serialise at ~11 ns each (MI355X_MICROARCH.md "dequeue": one word
+// saturates at ~88 per microsecond), and with a single counter that alone was 1.9 ms of the 3.3 ms primary-ray k_shade launch
+// of a 4096x4096 batch (164 k appends).  A segment receives at most ceil(T / kSegs) iterations of <= 512 rays, T =
+// ceil(input rays / 512), hence seg_cap = ceil(ceil(capacity / 512) / kSegs) * 512 never overflows.  Consumers number the
+// rays 0 .. total-1 across the segments in order (queue_view / queue_slot); per-path results do not depend on slot order.
+constexpr uint32_t kSegs = 8;
+constexpr uint32_t kSegPitch = 32;              // u32 words between two segment counters (128 B)
+struct Queue { uint32_t* n; uint32_t seg_cap; };  // n[k * kSegPitch] = rays in segment k
+struct QueueView { uint32_t pre[kSegs + 1]; uint32_t seg_cap; };     // pre[k] = rays before segment k, pre[kSegs] = total
+MIRT_DI QueueView queue_view(const Queue& q) {
+	QueueView v; v.seg_cap = q.seg_cap; v.pre[0] = 0;
+	for (uint32_t k = 0; k < kSegs; k++) v.pre[k + 1] = v.pre[k] + q.n[k * kSegPitch];     // wave-uniform: scalar loads
+	return v;
+}
+MIRT_DI QueueView queue_identity(uint32_t total) {     // bounce 0: ray i is slot i (the rays are generated from their index)
+	QueueView v; v.seg_cap = 0; v.pre[0] = 0;
+	for (uint32_t k = 1; k <= kSegs; k++) v.pre[k] = total;
+	return v;
+}
+// The piece [first, end) of the numbering that lies in first's segment, and the offset that turns its numbers into slots.
+struct QueuePiece { uint32_t end, offset; };
+MIRT_DI QueuePiece queue_piece(const QueueView& v, uint32_t first) {
+	uint32_t seg = 0, lo = 0, hi = v.pre[1];
+	for (uint32_t k = 1; k < kSegs; k++) { const bool ge = first >= v.pre[k]; seg = ge ? k : seg; lo = ge ? v.pre[k] : lo; hi = ge ? v.pre[k + 1] : hi; }
+	return QueuePiece{ hi, seg * v.seg_cap - lo };
+}
+// The same straight from the counters in memory (k_trace calls it once per reserved chunk of rays and keeps no view in registers:
+// the kernel sits at its 64-VGPR budget).  q.n == nullptr: the identity numbering of bounce 0, `total` rays.
+MIRT_DI QueuePiece queue_piece(const Queue& q, uint32_t total, uint32_t first) {
+	if (q.n == nullptr) return QueuePiece{ total, 0u };
+	uint32_t lo = 0, seg = 0, end = 0;
+	for (uint32_t k = 0; k < kSegs; k++) {
+		const uint32_t cnt = q.n[k * kSegPitch];
+		if (first >= lo + cnt && k + 1 < kSegs) { lo += cnt; continue; }
+		seg = k; end = lo + cnt; break;
+	}
+	return QueuePiece{ end, seg * q.seg_cap - lo };
+}
+MIRT_DI uint32_t queue_total(const Queue& q) { uint32_t t = 0; for (uint32_t k = 0; k < kSegs; k++) t += q.n[k * kSegPitch]; return t; }
+MIRT_DI uint32_t queue_slot(const QueueView& v, uint32_t i) { return i + queue_piece(v, i).offset; }     // per-lane form
+// The same for consecutive numbers starting at the wave-uniform `first`: scalar segment search, per-lane work only for the
+// lanes (if any) that fall into a later segment.
+MIRT_DI uint32_t queue_slot(const QueueView& v, uint32_t first, uint32_t i) {
+	const QueuePiece p = queue_piece(v, first);
+	return i < p.end ? i + p.offset : queue_slot(v, i);
+}
+
+// Two-queue compaction for a whole workgroup: wave64 ballots give per-wave counts, one lane per queue adds the workgroup
+// total to the counter of segment `seg` (ONE global atomic per queue per `blockDim.x` rays), and every lane gets
+// segment start + base + (counts of earlier waves) + (rank inside its wave).  Must be called by all threads of the block,
+// converged.  `scratch` = 2*2*16+2*2 words of LDS, double-buffered on `parity` so consecutive calls need no third barrier.
+MIRT_DI void block_append2(bool flag_a, bool flag_b, const Queue& qa, const Queue& qb, uint32_t seg, uint32_t* scratch, uint32_t parity,
                            uint32_t& slot_a, uint32_t& slot_b) {
 	const unsigned long long ma = __ballot(flag_a), mb = __ballot(flag_b);
 	const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = lane_id();
@@ -126,10 +176,10 @@ MIRT_DI void block_append2(bool flag_a, bool flag_b, uint32_t* counter_a, uint32
 		const uint32_t* cnt = threadIdx.x ? cnt_b : cnt_a;
 		uint32_t total = 0;
 		for (uint32_t w = 0; w < n_waves; w++) total += cnt[w];
-		base[threadIdx.x] = total ? atomicAdd(threadIdx.x ? counter_b : counter_a, total) : 0u;
+		base[threadIdx.x] = total ? atomicAdd((threadIdx.x ? qb.n : qa.n) + seg * kSegPitch, total) : 0u;
 	}
 	__syncthreads();
-	uint32_t pa = base[0], pb = base[1];
+	uint32_t pa = base[0] + seg * qa.seg_cap, pb = base[1] + seg * qb.seg_cap;
 	for (uint32_t w = 0; w < wave; w++) { pa += cnt_a[w]; pb += cnt_b[w]; }
 	slot_a = pa + mask_rank(ma);
 	slot_b = pb + mask_rank(mb);
@@ -410,12 +460,14 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 // [wbeg, wend) that it reserves from a per-launch work counter (one atomic per kChunk rays); whenever at least
 // kRefillIdle lanes are idle they are given the next rays of the window — slot = wbeg + rank among idle lanes, from a
 // wave64 ballot + mbcnt prefix sum — and the wave goes back to stepping all lanes together.
-constexpr uint32_t kChunkMax = 512;
+constexpr uint32_t kChunkMax = 4096;   // (the work counter is one word as well: 164 k reservations of 512 rays were a 1.9 ms floor under the 84 M-ray launches)
 constexpr uint32_t kRefillIdle = 32;   // measured on cfg2: 8 -> 15.3 ms of trace per step, 16 -> 13.9, 24..40 -> 13.5 (a refill runs the ~200-instruction ray set-up on the whole wave)
 constexpr uint32_t kNone = 0xffffffffu;
 struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
-struct WaveWindow { uint32_t beg, end, chunk; bool more; };
-// Rays per reservation: large enough that the work counter sees one atomic per several hundred rays, small enough that
+// [beg, end): ray numbers the wave still has to hand out, all in one queue segment (slot = number + offset); [end, chunk_end):
+// the rest of the reserved chunk, in later segments.
+struct WaveWindow { uint32_t beg, end, chunk_end, offset, chunk; bool more; };
+// Rays per reservation: large enough that the work counter sees one atomic per a few thousand rays, small enough that
 // every wave of the grid gets a few chunks even on the thin late-bounce streams.
 MIRT_DI uint32_t pick_chunk(uint32_t n) {
 	const uint32_t waves = gridDim.x * (blockDim.x >> 6);
@@ -423,22 +475,28 @@ MIRT_DI uint32_t pick_chunk(uint32_t n) {
 	c = (c + 63u) & ~63u;
 	return c < 64u ? 64u : (c > kChunkMax ? kChunkMax : c);
 }
-// Gives the lanes with `want` the next ray indices of the wave's window (slot = beg + rank among wanting lanes, from a
+// Gives the lanes with `want` the slots of the next rays of the wave's window (number = beg + rank among wanting lanes, from a
 // wave64 ballot + mbcnt prefix sum), reserving a new chunk from the launch's work counter when the window is empty.
-MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_next) {
+MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n, uint32_t* work_next) {
 	const unsigned long long m = __ballot(want);
 	const uint32_t n_want = static_cast<uint32_t>(__popcll(m));
 	if (n_want == 0u) return kNone;
-	if (w.beg == w.end && w.more) {
-		uint32_t base = 0;
-		if (lane_id() == 0) base = atomicAdd(work_next, w.chunk);
-		base = __builtin_amdgcn_readfirstlane(base);
-		if (base >= n) { w.more = false; w.beg = w.end = 0; }
-		else { w.beg = base; w.end = min(base + w.chunk, n); }
+	if (w.beg == w.end) {
+		if (w.end == w.chunk_end && w.more) {
+			uint32_t base = 0;
+			if (lane_id() == 0) base = atomicAdd(work_next, w.chunk);
+			base = __builtin_amdgcn_readfirstlane(base);
+			if (base >= n) { w.more = false; w.beg = w.end = w.chunk_end = 0; }
+			else { w.beg = w.end = base; w.chunk_end = min(base + w.chunk, n); }
+		}
+		if (w.end != w.chunk_end) {                                  // next piece of the chunk: the part that lies in one segment
+			const QueuePiece p = queue_piece(q, n, w.beg);
+			w.end = min(w.chunk_end, p.end); w.offset = p.offset;
+		}
 	}
 	const uint32_t take = min(n_want, w.end - w.beg);
 	uint32_t got = kNone;
-	if (want) { const uint32_t r = mask_rank(m); if (r < take) got = w.beg + r; }
+	if (want) { const uint32_t r = mask_rank(m); if (r < take) got = w.beg + r + w.offset; }
 	w.beg += take;
 	return got;
 }
@@ -450,9 +508,9 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, uint32_t n, uint32_t* work_
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
 template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
-MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
+MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
-	WaveWindow w{ 0, 0, pick_chunk(n), true };
+	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n), true };
 	Trav t;
 	TravSpill spill;
 	uint32_t ri = kNone;
@@ -461,7 +519,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n,
 		// ---- refill event: flush results, hand the idle lanes the next ray indices of the window, load and set up their rays ----
 		if (done) { store_result(ri, t, occluded); done = false; ri = kNone; }
 		{
-			const uint32_t got = wave_take(ri == kNone, w, n, work_next);
+			const uint32_t got = wave_take(ri == kNone, w, q, n, work_next);   // a slot of the stream planes
 			if (got != kNone) {
 				float px, py, pz, dx, dy, dz, tf;
 				load_ray(got, px, py, pz, dx, dy, dz, tf);
@@ -472,7 +530,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, uint32_t n,
 				}
 			}
 		}
-		const bool work_left = w.more || w.beg != w.end;
+		const bool work_left = w.more || w.beg != w.chunk_end;
 		if (__ballot(ri != kNone) == 0ull) { if (!work_left) break; continue; }
 		const bool can_refill = work_left;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
@@ -592,17 +650,17 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // ------------------------------------------------------------------------------------------------
 // Drain one ray queue with the persistent-wave loop (dispatch on the staged-BVH variant).
 template <bool ANYHIT, bool COUNT, class LoadRay, class StoreResult>
-MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
+MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                          LoadRay load_ray, StoreResult store_result) {
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
-		if (!sc.stack16) trace_persistent<ANYHIT, COUNT, false, true, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);   // > 65535 records: never all in LDS
-		else if (all) trace_persistent<ANYHIT, COUNT, true, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, true, true>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (!sc.stack16) trace_persistent<ANYHIT, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);   // > 65535 records: never all in LDS
+		else if (all) trace_persistent<ANYHIT, COUNT, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	} else {
-		if (all) trace_persistent<ANYHIT, COUNT, true, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, false, false>(sc, tl, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (all) trace_persistent<ANYHIT, COUNT, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		else trace_persistent<ANYHIT, COUNT, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
 	}
 }
 
@@ -675,12 +733,13 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 template <bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FrameParams fp,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
-                                                       const uint32_t* __restrict__ closest_count, uint32_t* closest_work,
+                                                       Queue closest_queue, uint32_t* closest_work,
                                                        ShadowBuf sh, ShadowSink sink,
-                                                       const uint32_t* __restrict__ shadow_count, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
+                                                       Queue shadow_queue, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
                                                        DevCounters* ctr) {
 	extern __shared__ float4 lds[];
-	const uint32_t nc = PRIMARY ? fp.n_pix * fp.batch_n : *closest_count, ns = PRIMARY ? 0u : *shadow_count;
+	if (PRIMARY) closest_queue.n = nullptr;                                    // identity numbering: ray i is slot i
+	const uint32_t nc = PRIMARY ? fp.n_pix * fp.batch_n : queue_total(closest_queue), ns = PRIMARY ? 0u : queue_total(shadow_queue);
 	if (nc + ns == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		if (nc) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));
@@ -697,20 +756,22 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 				tf = MIRT_FLT_MAX;                                                 // hit reset, Renderer.hpp:150-158
 			};
 			auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
-			trace_queue<false, COUNT>(sc, tl, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
+			trace_queue<false, COUNT>(sc, tl, closest_queue, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
 		if (!PRIMARY) {
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
 				shadow_origin(sh, sink, i, px, py, pz); dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 			};
 			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { shadow_finish(sh, sink, i, occluded, c_term); };
-			trace_queue<true, COUNT>(sc, tl, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
+			trace_queue<true, COUNT>(sc, tl, shadow_queue, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
 		}
 	} else {
 		// brute force over all prims (the reference as shipped); also the no-spheres case
+		const QueueView qc = PRIMARY ? queue_identity(nc) : queue_view(closest_queue);
+		const QueueView qs = PRIMARY ? queue_identity(0u) : queue_view(shadow_queue);
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < nc; base += gridDim.x * kTraceBlock) {
-			const uint32_t i = base + threadIdx.x;
-			const bool active = i < nc;
+			const bool active = base + threadIdx.x < nc;
+			const uint32_t i = active ? queue_slot(qc, base, base + threadIdx.x) : 0u;
 			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1;
 			if (active) {
 				if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
@@ -722,8 +783,8 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 			if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
 		}
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < ns; base += gridDim.x * kTraceBlock) {
-			const uint32_t i = base + threadIdx.x;
-			const bool active = i < ns;
+			const bool active = base + threadIdx.x < ns;
+			const uint32_t i = active ? queue_slot(qs, base, base + threadIdx.x) : 0u;
 			float px = 0, py = 0, pz = 0, dx = 1, dy = 1, dz = 1, tfar = 0;
 			if (active) { shadow_origin(sh, sink, i, px, py, pz); dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tfar = sh.tfar[i]; }
 			bool occluded = false;
@@ -821,10 +882,9 @@ MIRT_DI uint32_t block_compact(bool flag, uint32_t value, uint32_t* scratch, uin
 template <bool FIRST>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
                                                   const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
-                                                  uint32_t* stream_count, uint32_t* shadow_count, float* __restrict__ accum, DevCounters* ctr) {
-	const uint32_t n = FIRST ? fp.n_pix * fp.batch_n : stream_count[bounce];
-	uint32_t* next_count = &stream_count[bounce + 1];
-	uint32_t* sh_count = &shadow_count[bounce];
+                                                  Queue in_queue, Queue next_queue, Queue shadow_queue, float* __restrict__ accum, DevCounters* ctr) {
+	const QueueView qin = FIRST ? queue_identity(fp.n_pix * fp.batch_n) : queue_view(in_queue);
+	const uint32_t n = qin.pre[kSegs];
 	const bool last_bounce = !(bounce < fp.max_bounces - 1u);                 // Renderer.hpp:358
 	const float light_selection_pdf = 1.0f / static_cast<float>(fp.n_lights);  // Renderer.hpp:78
 	__shared__ uint32_t append_scratch[72];
@@ -839,9 +899,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	for (uint32_t base = blockIdx.x * kShadeBlock; base < n; base += gridDim.x * kShadeBlock, parity ^= 1u) {
 		// ---- phase 1, one lane per ray of the stream: misses end here; hits are only listed ----
 		bool is_hit = false;
+		const uint32_t my_slot = (base + threadIdx.x < n) ? queue_slot(qin, base, base + threadIdx.x) : 0u;     // this lane's ray of the stream
 		{
-			const uint32_t i = base + threadIdx.x;
-			if (i < n) {
+			if (base + threadIdx.x < n) {
+				const uint32_t i = my_slot;
 				const int32_t prim = prim_in[i];
 				if (prim < 0) {
 					// MISS SHADER, Renderer.hpp:408-420 (Q10: throughput.r scales all three channels)
@@ -865,7 +926,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		// ---- regroup: the closest-hit shader is ~800 VALU instructions per ray and only 40-60 % of a secondary stream hits;
 		// packing the hits of the block into its first waves runs that code on full waves (lane utilisation 0.42 -> ~0.9) ----
 		// (Not for primary rays: ~95 % of them hit, the stream is already dense, and the two barriers cost more than they save.)
-		const uint32_t n_hits = FIRST ? 0u : block_compact(is_hit, base + threadIdx.x, compact_scratch, hit_list);
+		const uint32_t n_hits = FIRST ? 0u : block_compact(is_hit, my_slot, compact_scratch, hit_list);
 
 		// ---- phase 2, one lane per hit ----
 		bool survive = false, has_shadow = false, terminated = false, has_E = false;
@@ -874,7 +935,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		f3 R{0.0f, 0.0f, 0.0f}, thr{1.0f, 1.0f, 1.0f};
 		float npdf = 0.0f, light_distance = 0.0f;
 		if (FIRST ? is_hit : threadIdx.x < n_hits) {
-			const uint32_t i = FIRST ? base + threadIdx.x : hit_list[threadIdx.x];
+			const uint32_t i = FIRST ? my_slot : hit_list[threadIdx.x];
 			f3 D;
 			if (FIRST) primary_ray(fp, i, path, D.x, D.y, D.z);                  // bounce 0 has no stream: the ray is a function of its index
 			else { path = in.path[i]; D = { in.dx[i], in.dy[i], in.dz[i] }; }
@@ -975,7 +1036,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		}
 		// ---- stream compaction: wave64 ballot + mbcnt prefix inside each wave, one atomic per workgroup and stream ----
 		uint32_t slot, sslot;
-		block_append2(survive, has_shadow, next_count, sh_count, append_scratch, parity, slot, sslot);
+		block_append2(survive, has_shadow, next_queue, shadow_queue, (base / kShadeBlock) % kSegs, append_scratch, parity, slot, sslot);
 		// (R + unoccluded NEE) + E is finished by k_trace's shadow_finish once the occlusion is known.  Non-emissive hits (E = +0)
 		// leave R where that result belongs and send a light record; the others send R and E along (kDestFull).
 		const bool direct = fp.idx_base != 0xffffffffu;                          // paths add straight into accumulator words that hold earlier samples

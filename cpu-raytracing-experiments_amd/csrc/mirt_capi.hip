@@ -57,7 +57,7 @@ struct TimedLaunch { int klass; hipEvent_t start, stop; };
 struct PipeSlot {
 	hipStream_t stream = nullptr;
 	DeviceBuffer arena;              // ray streams
-	DeviceBuffer counts;             // stream_count[nb+1] | shadow_count[nb] | work_next[nb] | work_next_shadow[nb] | zero word
+	DeviceBuffer counts;             // ray queues (kSegs counters each): stream[nb+1] | shadow[nb] | one always-empty queue; then work_next[nb] | work_next_shadow[nb] | fat counts[2 nb]
 	DeviceBuffer contrib;            // this batch's adds, same layout as the accumulator
 	DeviceBuffer fat;                // fat-ray index lists: [closest kFatCapacity][shadow kFatCapacity]
 	hipEvent_t batch_done = nullptr; // recorded on `stream` after the batch's last kernel
@@ -99,13 +99,14 @@ struct mirt_ctx {
 	size_t frame_host_bytes = 0;
 	DeviceBuffer counters;           // DevCounters
 	std::vector<PipeSlot> slots;     // batches in flight (policy.streams)
-	uint32_t capacity = 0;           // rays per stream plane
+	uint32_t capacity = 0;           // rays per stream plane (= kSegs * seg_cap)
+	uint32_t seg_cap = 0;            // slots per queue segment
 	uint32_t arena_bounces = 0;
 	uint64_t batch_seq = 0;
 
 	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
 	// launch-shape knobs for measurements (profiles/experiments/*): MIRT_TUNE_TRACE_WGS / MIRT_TUNE_SHADE_WGS = workgroups per CU
-	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3;
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_treelets = 1;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -173,6 +174,8 @@ hipError_t sync_all(mirt_ctx* c) {
 	for (PipeSlot& sl : c->slots) if (sl.stream) { hipError_t e = hipStreamSynchronize(sl.stream); if (e != hipSuccess) return e; }
 	return hipStreamSynchronize(c->stream);
 }
+constexpr uint32_t kQueueWords = kSegs * kSegPitch;     // one ray queue's counters
+size_t counts_words(uint32_t nb) { return static_cast<size_t>(2 * nb + 2) * kQueueWords + static_cast<size_t>(nb) * 4 + 8; }
 constexpr uint32_t kFatCapacity = 1u << 16;   // rays per list and launch that may take the brute-force detour (a few per million qualify)
 uint32_t wanted_slots(const mirt_ctx* c) { const uint32_t s = c->policy.streams ? c->policy.streams : 3u; return s > 8u ? 8u : s; }
 
@@ -182,8 +185,10 @@ int ensure_streams(mirt_ctx* c) {
 	const uint64_t cap64 = n_pix * batch_limit(c);
 	if (cap64 == 0) return MIRT_OK;
 	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
-	if (cap64 > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
-	const uint32_t cap = static_cast<uint32_t>(cap64);
+	if (cap64 + kSegs * kShadeBlock > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
+	// a ray queue is kSegs segments of seg_cap slots (kernels.hpp "ray queues"): a plane holds kSegs * seg_cap entries
+	const uint32_t seg_cap = static_cast<uint32_t>(((cap64 + kShadeBlock - 1) / kShadeBlock + kSegs - 1) / kSegs * kShadeBlock);
+	const uint32_t cap = seg_cap * kSegs;
 	const uint32_t nb = c->policy.max_bounces;
 	const uint32_t want = wanted_slots(c);
 	const bool contrib = uses_contrib(c, want);
@@ -210,7 +215,7 @@ int ensure_streams(mirt_ctx* c) {
 	for (PipeSlot& sl : c->slots) {
 		sl.in_use = false;
 		HIP_TRY(c, sl.arena.ensure(planes * plane_bytes));
-		HIP_TRY(c, sl.counts.ensure((static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t)));
+		HIP_TRY(c, sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)));
 		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 		if (contrib) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
 		char* p = sl.arena.as<char>();
@@ -233,6 +238,7 @@ int ensure_streams(mirt_ctx* c) {
 		h.dest = (uint32_t*)take();
 	}
 	c->capacity = cap;
+	c->seg_cap = seg_cap;
 	c->arena_bounces = nb;
 	return MIRT_OK;
 }
@@ -317,13 +323,14 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const bool contrib = uses_contrib(c, static_cast<uint32_t>(c->slots.size()));
 	const size_t contrib_floats = static_cast<size_t>(c->n_tiles) * batch_n * 3 * kTileSize;     // [tile][slot][rgb][256]
 	if (contrib) { fp.idx_base = 0xffffffffu; fp.idx_buckets = batch_n; }            // bucket of slot k inside the buffer = k
-	uint32_t* stream_count = sl.counts.as<uint32_t>();
-	uint32_t* shadow_count = stream_count + nb + 1;
-	uint32_t* work_next = shadow_count + nb;            // per-launch work counters of the persistent trace kernels
+	uint32_t* counts = sl.counts.as<uint32_t>();
+	auto stream_queue = [&](uint32_t b) { return Queue{ counts + static_cast<size_t>(b) * kQueueWords, c->seg_cap }; };                 // rays entering bounce b (b >= 1)
+	auto shadow_queue = [&](uint32_t b) { return Queue{ counts + static_cast<size_t>(nb + 1 + b) * kQueueWords, c->seg_cap }; };        // NEE rays emitted at bounce b
+	const Queue empty_queue{ counts + static_cast<size_t>(2 * nb + 1) * kQueueWords, c->seg_cap };                                      // "no shadow rays pending"
+	uint32_t* work_next = counts + static_cast<size_t>(2 * nb + 2) * kQueueWords;     // per-launch work counters of the persistent trace kernels
 	uint32_t* work_next_shadow = work_next + nb;
 	uint32_t* fat_n_closest = work_next_shadow + nb;    // per-launch fat-ray counts (closest-hit list, shadow list)
 	uint32_t* fat_n_shadow = fat_n_closest + nb;
-	const uint32_t* zero_count = fat_n_shadow + nb;     // an always-zero count ("no shadow rays pending")
 	DevCounters* ctr = c->counters.as<DevCounters>();
 	float* accum = contrib ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
@@ -332,33 +339,35 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t tgrid = trace_grid(c, total);
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
 	const uint32_t tlds = trace_lds(c);
+	// one workgroup per fat ray: a large scene (100 k spheres: ~100 us per ray) wants as many of them in flight as there are rays (a few hundred per launch)
+	const uint32_t fat_grid = sc.n_spheres > 4096 ? static_cast<uint32_t>(c->n_cu) * 2u : 64u;
 
 	if (pipelined && sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));   // the slot's previous batch has been merged: buffers are free
 	if (contrib) HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, contrib_floats * sizeof(float), st));
-	HIP_TRY(c, hipMemsetAsync(stream_count, 0, (static_cast<size_t>(nb) * 6 + 8) * sizeof(uint32_t), st));
+	HIP_TRY(c, hipMemsetAsync(counts, 0, counts_words(nb) * sizeof(uint32_t), st));
 	// bounce 0 has no ray stream: k_trace<PRIMARY> and k_shade<FIRST> derive the camera ray from its index (RAY GENERATION, Renderer.hpp:113-127)
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
 		const StreamBuf& in = sl.stream_buf[bounce & 1u];
 		const StreamBuf& out = sl.stream_buf[(bounce & 1u) ^ 1u];
 		const bool shadow_pending = fp.mis && bounce > 0;           // NEE rays emitted by k_shade(bounce-1)
 		{ Bracket t(c, MIRT_K_TRACE, st);
-		  const uint32_t* sc_count = shadow_pending ? shadow_count + (bounce - 1) : zero_count;
+		  const Queue sq = shadow_pending ? shadow_queue(bounce - 1) : empty_queue;
 		  uint32_t* sc_work = work_next_shadow + (shadow_pending ? bounce - 1 : 0);
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
 		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, nullptr };
 		  auto launch_trace = [&](auto kernel, auto fat_kernel) {
-		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, stream_count + bounce, work_next + bounce,
-		                       sl.shadow_buf, sink, sc_count, sc_work, fc, fs, ctr);
+		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, stream_queue(bounce), work_next + bounce,
+		                       sl.shadow_buf, sink, sq, sc_work, fc, fs, ctr);
 		    // the few rays too "fat" for the tree: brute force, one workgroup each
-		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(64), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
+		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
 		  };
 		  if (bounce == 0) { if (count) launch_trace(k_trace<true, true>, k_trace_fat<true, true>); else launch_trace(k_trace<false, true>, k_trace_fat<false, true>); }
 		  else             { if (count) launch_trace(k_trace<true, false>, k_trace_fat<true, false>); else launch_trace(k_trace<false, false>, k_trace_fat<false, false>); } }
 		{ Bracket t(c, MIRT_K_SHADE, st);
-		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr);
-		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_count, shadow_count, accum, ctr); }
+		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr);
+		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr); }
 	}
 	HIP_TRY(c, hipGetLastError());
 	if (contrib) {
@@ -422,6 +431,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	if (e != hipSuccess) return fail(nullptr, MIRT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
 	mirt_ctx* c = new mirt_ctx();
 	c->device = device;
+	if (const char* e = std::getenv("MIRT_TUNE_TREELETS")) c->tune_treelets = std::atoi(e) != 0;
 	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
 	if (const char* e = std::getenv("MIRT_TUNE_SHADE_WGS")) c->tune_shade_wgs = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 16));
 	hipDeviceProp_t prop;
@@ -537,18 +547,30 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 			return fail(c, MIRT_ERR_HIP, "GPU BVH build: %s", why.c_str());
 		if (depth > kStack) return fail(c, MIRT_ERR_ARG, "GPU-built BVH is %u levels deep (limit %u): set policy.gpu_build = 0 for this scene", depth, kStack);
 	} else {
-		if (c->policy.reference_tree || n_spheres == 0) {
+		std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
+		const bool caller_tree = c->policy.reference_tree || n_spheres == 0;
+		if (caller_tree) {
 			// traverse the caller's tree exactly as handed over (BVH.hpp:18-31 nodes over the BVH-order prims)
-			std::vector<mirt_bvh_node> own(nodes, nodes + n_nodes);
+			own.assign(nodes, nodes + n_nodes);
 			mirt_host::split_multi_prim_leaves(own);                         // the kernels know one-prim leaves only
-			const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth);
-			if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH rejected: %s", why.c_str());
 		} else {
 			// default: GPU-internal SAH tree over the same BVH-order prims (hit.primID keeps its meaning; results are identical)
-			std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
 			mirt_host::build_sah_tree(bvh_prims, n_spheres, own, prim_of_slot);
-			const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, &prim_of_slot);
-			if (!why.empty()) return fail(c, MIRT_ERR_ARG, "internal BVH rejected: %s", why.c_str());
+		}
+		const std::vector<uint32_t>* slot_map = caller_tree ? nullptr : &prim_of_slot;
+		auto layout = [&](uint32_t n_top) { return mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, slot_map, n_top); };
+		std::string why = layout(0xffffffffu);
+		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "%s BVH rejected: %s", caller_tree ? "caller's" : "internal", why.c_str());
+		// a tree too large for the LDS staging budget: breadth-first for the staged block only, treelets below it (bvh_layout.hpp)
+		{
+			const uint32_t n_all = static_cast<uint32_t>(recs.size() / 16);
+			std::vector<uint32_t> probe;
+			const bool half_ok = c->allow_half && mirt_host::build_half_records(recs, probe);
+			const uint32_t rec_bytes = half_ok ? 32u : 64u, budget = stage_budget(half_ok, half_ok && n_all <= 65535);
+			if (c->tune_treelets && static_cast<uint64_t>(n_all) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u > budget) {
+				why = layout(budget / rec_bytes);
+				if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH layout: %s", why.c_str());
+			}
 		}
 		n_recs = static_cast<uint32_t>(recs.size() / 16);
 		half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
@@ -818,24 +840,26 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	if (!p_xyz || !dir_xyz || !tfar_out || !prim_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	ScopedBuffer rays, res, cnt, ctr, fat;
-	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(32));
-	HIP_TRY(c, hipMemset(cnt.ptr, 0, 32));
+	constexpr size_t kCntWords = 2 * kQueueWords + 8;      // closest queue | shadow queue | work counter x2, fat count x2
+	HIP_TRY(c, rays.ensure(n * 6 * 4)); HIP_TRY(c, res.ensure(n * 8)); HIP_TRY(c, cnt.ensure(kCntWords * 4));
+	HIP_TRY(c, hipMemset(cnt.ptr, 0, kCntWords * 4));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
 	const uint32_t n32 = static_cast<uint32_t>(n);
-	HIP_TRY(c, hipMemcpy(cnt.ptr, &n32, 4, hipMemcpyHostToDevice));
+	uint32_t* cn = cnt.as<uint32_t>();
+	HIP_TRY(c, hipMemcpy(cn, &n32, 4, hipMemcpyHostToDevice));                 // all n rays in segment 0 of the closest queue: slot = ray number
 	StreamBuf in{};
 	in.px = d; in.py = d + n; in.pz = d + 2 * n; in.dx = d + 3 * n; in.dy = d + 4 * n; in.dz = d + 5 * n;
 	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
 	DevCounters* scratch_ctr = nullptr;
 	HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
-	// cnt = { n, work counter, 0 (no shadow rays), shadow work counter, fat count closest, fat count shadow }
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
-	const FatList fc{ cnt.as<uint32_t>() + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cnt.as<uint32_t>() + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
-	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), cnt.as<uint32_t>(), cnt.as<uint32_t>() + 1,
-	                   ShadowBuf{}, ShadowSink{}, cnt.as<uint32_t>() + 2, cnt.as<uint32_t>() + 3, fc, fs, scratch_ctr);
+	uint32_t* misc = cn + 2 * kQueueWords;
+	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
+	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
+	                   Queue{ cn, 0u }, misc, ShadowBuf{}, ShadowSink{}, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, scratch_ctr);
 	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -851,24 +875,26 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	if (!p_xyz || !dir_xyz || !tfar || !occluded_out || n == 0 || n >= (1ull << 31)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	ScopedBuffer rays, occ, cnt, ctr, fat;
-	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n * 4)); HIP_TRY(c, cnt.ensure(32)); HIP_TRY(c, ctr.ensure(sizeof(DevCounters)));
+	constexpr size_t kCntWords = 2 * kQueueWords + 8;      // closest queue (empty) | shadow queue | work counter x2, fat count x2
+	HIP_TRY(c, rays.ensure(n * 7 * 4)); HIP_TRY(c, occ.ensure(n * 4)); HIP_TRY(c, cnt.ensure(kCntWords * 4)); HIP_TRY(c, ctr.ensure(sizeof(DevCounters)));
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	float* d = rays.as<float>();
 	HIP_TRY(c, hipMemcpy(d, p_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 3 * n, dir_xyz, n * 12, hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMemcpy(d + 6 * n, tfar, n * 4, hipMemcpyHostToDevice));
-	// cnt = { 0 (no closest-hit rays), work counter, n, shadow work counter, fat count closest, fat count shadow }
-	const uint32_t host_cnt[8] = { 0, 0, static_cast<uint32_t>(n), 0, 0, 0, 0, 0 };
-	HIP_TRY(c, hipMemcpy(cnt.ptr, host_cnt, 32, hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMemset(cnt.ptr, 0, kCntWords * 4));
+	uint32_t* cn = cnt.as<uint32_t>();
+	const uint32_t n32 = static_cast<uint32_t>(n);
+	HIP_TRY(c, hipMemcpy(cn + kQueueWords, &n32, 4, hipMemcpyHostToDevice));   // all n rays in segment 0 of the shadow queue
 	HIP_TRY(c, hipMemset(ctr.ptr, 0, sizeof(DevCounters)));
 	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
 	ShadowBuf sh{}; sh.px = d; sh.py = d + n; sh.pz = d + 2 * n; sh.dx = d + 3 * n; sh.dy = d + 4 * n; sh.dz = d + 5 * n; sh.tfar = d + 6 * n;
-	uint32_t* cn = cnt.as<uint32_t>();
-	const FatList fc{ cn + 4, fat.as<uint32_t>(), kFatCapacity }, fs{ cn + 5, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
+	uint32_t* misc = cn + 2 * kQueueWords;
+	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
 	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
-	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), cn, cn + 1,
-	                   sh, sink, cn + 2, cn + 3, fc, fs, ctr.as<DevCounters>());
+	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
+	                   Queue{ cn, 0u }, misc, sh, sink, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, ctr.as<DevCounters>());
 	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
