@@ -37,9 +37,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue roof (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max
-# clock; the same product x 2 flop is the 157.3 TFLOP/s f32 vector peak).  Unit: 10^12 lane-instructions per second.
-VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
+# VALU issue roof: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz max clock — one wave64 VALU instruction per 4 cycles per SIMD.
+# (The chip's 157.3 TFLOP/s f32 vector peak = 64 FLOP/clk/SIMD is reached only by the PACKED form v_pk_fma_f32, two f32 lanes-ops per
+# lane and instruction: cdna_hip_programming.md §3 "Rate".  This path is per-lane scalar arithmetic — box and sphere tests with
+# different operands in every lane, compares, selects, integer hashing — none of which has a packed encoding, so its roof is the
+# unpacked issue rate.)  Unit: 10^12 lane-instructions per second; a wave64 instruction counts 64 lane slots whatever its exec mask.
+VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
 SQ_COUNTERS = "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY"
 
 
@@ -119,7 +122,7 @@ def collect_pmc(args, log):
     if sq is None:
         return None
     out["sq"], out["child"] = sq
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):              # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes
+    for name in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):   # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes; GRBM: the clock the chip held
         r = run_pmc_pass(name, args, log)
         out[name] = r[0] if r else None
     log(f"pmc passes took {time.perf_counter() - t0:.1f}s")
@@ -311,7 +314,7 @@ def main():
             traced = counts["rays"] + counts["shadow_rays"]
             ab = algorithmic_bytes(counts)
             roofline = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANE, "unit": "Tlane-inst/s", "frac": None, "traffic": None,
-                        "peak_definition": "256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz (= the 157.3 TFLOP/s f32 vector peak / 2 flop); a wave64 VALU instruction counts 64 lane slots",
+                        "peak_definition": "256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: one unpacked wave64 VALU instruction per 4 cycles per SIMD (the 157.3 TFLOP/s vector peak needs v_pk_fma_f32, which per-lane box/sphere tests, compares and selects cannot use); a wave64 instruction counts 64 lane slots",
                         "launches": tr["launches"], "avg_launch_ms": tr["ms"] / tr["launches"],
                         "measured_with": f"HIP events on the launch stream, second live pass of {aux} step(s) with one batch in flight",
                         "traced_rays_per_launch": traced / tr["launches"],
@@ -336,6 +339,12 @@ def main():
                                 note="achieved = VALU wave-instructions per traced ray (SQ_INSTS_VALU of the k_trace dispatches of one batch, this run's rocprofv3 --pmc child pass) "
                                      "x rays traced in the HIP-event pass x 64 lanes / k_trace time of that pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
                                      "useful_frac = frac x lane_utilisation")
+                gr = pmc.get("GRBM_GUI_ACTIVE")
+                if gr and "trace" in gr and gr["trace"]["us"] > 0:
+                    # MI355X_MICROARCH.md "DVFS give-back": effective clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
+                    ghz = gr["trace"]["GRBM_GUI_ACTIVE"] / 8.0 / (gr["trace"]["us"] * 1e-6) / 1e9
+                    roofline["clock_GHz_during_k_trace"] = ghz
+                    roofline["frac_at_that_clock"] = ach / (256 * 4 * 16 * ghz * 1e9 / 1e12)
                 f, w_ = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
                 if f and w_ and "trace" in f and "trace" in w_:
                     # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact; both in KB

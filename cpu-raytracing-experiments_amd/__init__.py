@@ -101,13 +101,38 @@ def load_library():
         "mirt_debug_info": [P, vp],
         "mirt_debug_allow_half_boxes": [P, i32],
     }
+    G = C.c_void_p
+    sigs.update({
+        "mirt_group_create": [vp, i32, C.POINTER(G)],
+        "mirt_group_destroy": [G],
+        "mirt_group_size": [G, C.POINTER(i32)],
+        "mirt_group_member": [G, i32, C.POINTER(P)],
+        "mirt_group_set_scene": [G, vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, vp, u32, u32],
+        "mirt_group_set_camera": [G, vp, vp, f, f, f, f],
+        "mirt_group_set_policy": [G, C.POINTER(Policy)],
+        "mirt_group_resize": [G, u32, u32],
+        "mirt_group_reset": [G],
+        "mirt_group_accumulate": [G, u32],
+        "mirt_group_accumulate_async": [G, u32],
+        "mirt_group_synchronize": [G],
+        "mirt_group_get_accumulations": [G, C.POINTER(u32)],
+        "mirt_group_get_counters": [G, C.POINTER(Counters)],
+        "mirt_group_gather": [G],
+        "mirt_group_last_gather_ms": [G, C.POINTER(C.c_double)],
+        "mirt_group_accumulator_floats": [G, C.POINTER(C.c_size_t)],
+        "mirt_group_read_accumulator": [G, vp],
+        "mirt_group_render": [G, vp],
+        "mirt_group_rccl_selftest": [i32, C.c_size_t],
+    })
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.mirt_last_error.argtypes = [P]
     lib.mirt_last_error.restype = C.c_char_p
-    lib._declared = tuple(sigs) + ("mirt_last_error",)
+    lib.mirt_group_last_error.argtypes = [P]
+    lib.mirt_group_last_error.restype = C.c_char_p
+    lib._declared = tuple(sigs) + ("mirt_last_error", "mirt_group_last_error")
     _lib = lib
     return lib
 
@@ -331,3 +356,118 @@ class Renderer:
         out = np.empty((n_out, n), dtype=np.float32)
         self._check(self._lib.mirt_debug_math(self._ctx, fn, n, _ptr(inputs), _ptr(out)))
         return out
+
+
+class GroupRenderer:
+    """The same `Renderer<Policy>` interface on several GPUs of one node, driven by this one process through the library's
+    mirt_group_* entry points (include/mirt.h): scene replicated, tile rows interleaved over the devices, one RCCL gather of the
+    accumulator slabs to devices[0] when a frame or the accumulator is read.  `devices` may repeat a device (rehearsal on a
+    one-GPU box; slabs then move with device copies)."""
+
+    def __init__(self, scene: Scene, devices=(0,), max_bounces: int = 16, buckets: int = 5, mis: bool = True, use_bvh: bool = True,
+                 count_traffic: bool = False, max_batch: int = 0, streams: int = 0, reference_tree: bool = False, gpu_build: bool = False):
+        self._lib = load_library()
+        self._g = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        rc = self._lib.mirt_group_create(dev, len(devices), C.byref(self._g))
+        if rc != MIRT_OK:
+            raise MirtError(f"mirt_group_create failed ({rc}): {self._lib.mirt_group_last_error(None).decode()}")
+        self.scene, self.devices = scene, tuple(devices)
+        self.width = self.height = 0
+        self.framebuffer = None
+        self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), 0, max_batch, int(reference_tree), int(streams), int(gpu_build))
+        self._check(self._lib.mirt_group_set_policy(self._g, C.byref(self.policy)))
+        self.UpdateScene()
+
+    def _check(self, rc):
+        if rc < 0:
+            raise MirtError(f"mirt_group call failed ({rc}): {self._lib.mirt_group_last_error(self._g).decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._lib.mirt_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def UpdateScene(self):
+        s = self.scene
+        self.geometry = np.ascontiguousarray(s.geometry, dtype=SPHERE)
+        self.material = np.ascontiguousarray(s.material, dtype=MATERIAL)
+        self.nodes, self.prims = bvh_build(self.geometry)
+        self.lights = light_list(self.geometry, self.material)
+        hdri = np.ascontiguousarray(s.hdri, dtype=np.float32)
+        amb = np.ascontiguousarray(s.ambient, dtype=np.float32)
+        lights = self.lights if len(self.lights) else np.zeros(1, dtype=np.int32)
+        self._check(self._lib.mirt_group_set_scene(self._g, _ptr(self.geometry), _ptr(self.prims), len(self.geometry), _ptr(self.nodes), len(self.nodes),
+                                                   _ptr(self.material), len(self.material), _ptr(lights), len(self.lights), _ptr(amb),
+                                                   _ptr(hdri), hdri.shape[1], hdri.shape[0]))
+        self.UpdateCamera()
+
+    def UpdateCamera(self):
+        cam: Camera = self.scene.camera
+        pos = np.ascontiguousarray(cam.pos, dtype=np.float32)
+        ori = np.ascontiguousarray(cam.orient, dtype=np.float32)
+        self._check(self._lib.mirt_group_set_camera(self._g, _ptr(pos), _ptr(ori), float(cam.half_width), float(cam.half_height), float(cam.z), float(cam.exposure)))
+
+    def Resize(self, new_width: int, new_height: int):
+        self.width, self.height = int(new_width), int(new_height)
+        self.scene.camera.resize(self.width, self.height)
+        self.UpdateCamera()
+        self._check(self._lib.mirt_group_resize(self._g, self.width, self.height))
+        self.framebuffer = np.zeros((self.height, self.width, 4), dtype=np.float32)
+
+    def ResetAccumulator(self):
+        self._check(self._lib.mirt_group_reset(self._g))
+
+    def Accumulate(self, n_calls: int = 1):
+        self._check(self._lib.mirt_group_accumulate(self._g, n_calls))
+
+    def AccumulateAsync(self, n_calls: int = 1):
+        self._check(self._lib.mirt_group_accumulate_async(self._g, n_calls))
+
+    def Synchronize(self):
+        self._check(self._lib.mirt_group_synchronize(self._g))
+
+    def Render(self) -> bool:
+        return self._check(self._lib.mirt_group_render(self._g, _ptr(self.framebuffer))) == MIRT_OK
+
+    def GetFrame(self) -> np.ndarray:
+        return self.framebuffer
+
+    @property
+    def accumulations(self) -> int:
+        v = C.c_uint32(0)
+        self._check(self._lib.mirt_group_get_accumulations(self._g, C.byref(v)))
+        return v.value
+
+    def accumulator(self) -> np.ndarray:
+        """The whole image's [tile][bucket][rgb][256] slab in LaunchIndex order (gathers first)."""
+        n = C.c_size_t(0)
+        self._check(self._lib.mirt_group_accumulator_floats(self._g, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._check(self._lib.mirt_group_read_accumulator(self._g, _ptr(out)))
+        return out.reshape(-1, self.policy.buckets, 3, 256)
+
+    def counters(self) -> dict:
+        c = Counters()
+        self._check(self._lib.mirt_group_get_counters(self._g, C.byref(c)))
+        return c.as_dict()
+
+    def gather_ms(self) -> float:
+        v = C.c_double(0.0)
+        self._check(self._lib.mirt_group_last_gather_ms(self._g, C.byref(v)))
+        return v.value
+
+
+def rccl_selftest(device: int = 0, n_floats: int = 1 << 20) -> None:
+    """mirt_group_rccl_selftest: raises if librccl cannot be loaded or a grouped ncclSend / ncclRecv on `device` does not deliver."""
+    lib = load_library()
+    rc = lib.mirt_group_rccl_selftest(device, n_floats)
+    if rc != MIRT_OK:
+        raise MirtError(f"RCCL self-test failed ({rc}): {lib.mirt_group_last_error(None).decode()}")

@@ -27,7 +27,6 @@
 #pragma once
 #include "../../include/mirt.h"
 
-#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -159,15 +158,13 @@ inline bool build_half_records(const std::vector<float>& recs, std::vector<uint3
 // `prim_of_slot` (optional): leaf slot s of `nodes` refers to prims[prim_of_slot[s]] (internal tree); without it slot s is
 // prims[s] (the caller's tree, BVH.hpp:201-205).  Leaf references always carry the index into `prims` (the BVH-order
 // array hit.primID refers to); mapped leaves must hold a single prim.
-// Record order: the first `n_top` records are numbered breadth-first (the block the trace kernels stage in LDS); the nodes below
-// them — fetched from L2 / HBM one dependent 32-B load per traversal step — are laid out in TREELETS: starting from a
-// subtree root, the four inner nodes most likely to be visited together (greedy by box half-area: the root, then always the
-// largest node on the frontier) get consecutive records, i.e. one 128-B line of binary16 records; the frontier's remaining
-// nodes root the next treelets, depth-first, so neighbouring treelets are neighbours in memory too.  A step into a child of
-// the same treelet then hits the line the lane has just pulled into its CU's L1 instead of going to L2.
+// Records are numbered breadth-first, so the top of the tree is one contiguous block (what the trace kernels stage in LDS).
+// (A treelet order for the records below that block — four likely-co-visited inner nodes per 128-B line, treelets laid out
+// depth-first — was measured on S(100000) and changed nothing: k_trace 399.9 ms/step breadth-first vs 405.0 with treelets; the
+// kernel is bound by VALU issue, not by where its L2 hits land.  Removed.)
 inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, const mirt_sphere* prims, uint32_t n_prims,
                                  std::vector<float>& recs /* 16 floats per record */, uint32_t* max_depth_out,
-                                 const std::vector<uint32_t>* prim_of_slot = nullptr, uint32_t n_top = 0xffffffffu) {
+                                 const std::vector<uint32_t>* prim_of_slot = nullptr) {
 	recs.clear();
 	*max_depth_out = 0;
 	if (n_nodes == 0) return "";
@@ -213,54 +210,22 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 		*max_depth_out = 1;
 		return "";
 	}
-	// breadth-first numbering of the first n_top inner nodes
+	// breadth-first numbering of inner nodes
 	std::vector<uint32_t> order;                           // record -> node
-	std::vector<uint32_t> rec_of(n_nodes, 0xffffffffu), depth(n_nodes, 0), deferred;
+	std::vector<uint32_t> rec_of(n_nodes, 0xffffffffu), depth(n_nodes, 0);
 	order.reserve(n_nodes / 2 + 1);
 	order.push_back(0); rec_of[0] = 0; depth[0] = 1;
-	bool shared = false;
-	auto number = [&](uint32_t c) {                         // gives inner node c the next record; false: it has one already (two parents)
-		if (rec_of[c] != 0xffffffffu || order.size() >= n_nodes) { shared = true; return false; }   // the size check also bounds every loop here
-		rec_of[c] = static_cast<uint32_t>(order.size()); order.push_back(c);
-		return true;
-	};
 	for (size_t head = 0; head < order.size(); head++) {
 		const uint32_t nd = order[head];
 		for (uint32_t c = nodes[nd].first_id; c <= nodes[nd].first_id + 1; c++) {
 			depth[c] = depth[nd] + 1;
 			if (depth[c] > *max_depth_out) *max_depth_out = depth[c];
-			if (nodes[c].prim_count != 0) continue;
-			if (order.size() < n_top) { if (!number(c)) return "node referenced by more than one parent"; }
-			else deferred.push_back(c);                     // roots of the subtrees below the breadth-first block, in breadth-first order
-		}
-	}
-	// treelets for the rest
-	if (!deferred.empty()) {
-		auto half_area = [&](uint32_t nd) { const PadBox& b = box[nd]; const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2]; return dx * dy + dy * dz + dz * dx; };
-		constexpr size_t kTreelet = 4;                      // binary16 records per 128-B line
-		std::vector<uint32_t> roots(deferred.rbegin(), deferred.rend()), frontier;     // stack: first deferred root on top
-		size_t guard = 0;
-		while (!roots.empty()) {
-			if (++guard > static_cast<size_t>(n_nodes) + 1) return "node referenced by more than one parent";
-			frontier.assign(1, roots.back()); roots.pop_back();
-			for (size_t k = 0; k < kTreelet && !frontier.empty(); k++) {
-				size_t best = 0;
-				for (size_t f = 1; f < frontier.size(); f++) if (half_area(frontier[f]) > half_area(frontier[best])) best = f;
-				const uint32_t nd = frontier[best];
-				frontier.erase(frontier.begin() + static_cast<long>(best));
-				if (!number(nd)) return "node referenced by more than one parent";
-				for (uint32_t c = nodes[nd].first_id; c <= nodes[nd].first_id + 1; c++) {
-					depth[c] = depth[nd] + 1;
-					if (depth[c] > *max_depth_out) *max_depth_out = depth[c];
-					if (nodes[c].prim_count == 0) frontier.push_back(c);
-				}
+			if (nodes[c].prim_count == 0) {
+				if (rec_of[c] != 0xffffffffu || order.size() >= n_nodes) return "node referenced by more than one parent";   // also bounds this loop
+				rec_of[c] = static_cast<uint32_t>(order.size()); order.push_back(c);
 			}
-			// what is left roots the following treelets; the largest goes on top of the stack (laid out next)
-			std::sort(frontier.begin(), frontier.end(), [&](uint32_t a, uint32_t b) { return half_area(a) < half_area(b); });
-			for (uint32_t f : frontier) roots.push_back(f);
 		}
 	}
-	if (shared) return "node referenced by more than one parent";
 	if (*max_depth_out >= MIRT_BVH_STACK) return "tree deeper than the 64-entry traversal stack (BVH.hpp:321)";
 	recs.assign(order.size() * 16, 0.0f);
 	for (size_t r = 0; r < order.size(); r++) {

@@ -47,7 +47,7 @@ struct SceneDev {
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
-	uint32_t _unused0;          // (leaves always hold one prim here: a caller's multi-prim leaves are split on the host, bvh_layout.hpp)
+	uint32_t chunk_max;         // rays per reservation from a launch's work counter, upper limit (pick_chunk)
 	uint32_t stack16;           // 1: record indices fit 16 bits and the LDS stack holds u16 entries (binary16 records, <= 65535 of them)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
@@ -460,7 +460,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 // [wbeg, wend) that it reserves from a per-launch work counter (one atomic per kChunk rays); whenever at least
 // kRefillIdle lanes are idle they are given the next rays of the window — slot = wbeg + rank among idle lanes, from a
 // wave64 ballot + mbcnt prefix sum — and the wave goes back to stepping all lanes together.
-constexpr uint32_t kChunkMax = 4096;   // (the work counter is one word as well: 164 k reservations of 512 rays were a 1.9 ms floor under the 84 M-ray launches)
+constexpr uint32_t kChunkMax = 512;    // default of SceneDev::chunk_max.  Measured (k_trace ms per step, 256 / 512 / 4096): cfg2 14.9 / 13.6 / 14.1, cfg4 - / 381.5 / 402.3 (larger chunks: uneven tails)
 constexpr uint32_t kRefillIdle = 32;   // measured on cfg2: 8 -> 15.3 ms of trace per step, 16 -> 13.9, 24..40 -> 13.5 (a refill runs the ~200-instruction ray set-up on the whole wave)
 constexpr uint32_t kNone = 0xffffffffu;
 struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
@@ -469,11 +469,11 @@ struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
 struct WaveWindow { uint32_t beg, end, chunk_end, offset, chunk; bool more; };
 // Rays per reservation: large enough that the work counter sees one atomic per a few thousand rays, small enough that
 // every wave of the grid gets a few chunks even on the thin late-bounce streams.
-MIRT_DI uint32_t pick_chunk(uint32_t n) {
+MIRT_DI uint32_t pick_chunk(uint32_t n, uint32_t chunk_max) {
 	const uint32_t waves = gridDim.x * (blockDim.x >> 6);
 	uint32_t c = n / (waves * 4u);
 	c = (c + 63u) & ~63u;
-	return c < 64u ? 64u : (c > kChunkMax ? kChunkMax : c);
+	return c < 64u ? 64u : (c > chunk_max ? chunk_max : c);
 }
 // Gives the lanes with `want` the slots of the next rays of the wave's window (number = beg + rank among wanting lanes, from a
 // wave64 ballot + mbcnt prefix sum), reserving a new chunk from the launch's work counter when the window is empty.
@@ -510,7 +510,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n,
 template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result) {
-	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n), true };
+	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n, sc.chunk_max), true };
 	Trav t;
 	TravSpill spill;
 	uint32_t ri = kNone;

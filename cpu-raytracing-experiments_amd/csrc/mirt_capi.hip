@@ -106,7 +106,7 @@ struct mirt_ctx {
 
 	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
 	// launch-shape knobs for measurements (profiles/experiments/*): MIRT_TUNE_TRACE_WGS / MIRT_TUNE_SHADE_WGS = workgroups per CU
-	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_treelets = 1;
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -335,6 +335,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	float* accum = contrib ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
 	sc.use_bvh = c->policy.use_bvh;
+	sc.chunk_max = c->tune_chunk;
 	const bool count = c->policy.count_traffic != 0;
 	const uint32_t tgrid = trace_grid(c, total);
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
@@ -431,7 +432,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	if (e != hipSuccess) return fail(nullptr, MIRT_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
 	mirt_ctx* c = new mirt_ctx();
 	c->device = device;
-	if (const char* e = std::getenv("MIRT_TUNE_TREELETS")) c->tune_treelets = std::atoi(e) != 0;
+	if (const char* e = std::getenv("MIRT_TUNE_CHUNK")) c->tune_chunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 65536)) & ~63u;
 	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
 	if (const char* e = std::getenv("MIRT_TUNE_SHADE_WGS")) c->tune_shade_wgs = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 16));
 	hipDeviceProp_t prop;
@@ -558,20 +559,8 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 			mirt_host::build_sah_tree(bvh_prims, n_spheres, own, prim_of_slot);
 		}
 		const std::vector<uint32_t>* slot_map = caller_tree ? nullptr : &prim_of_slot;
-		auto layout = [&](uint32_t n_top) { return mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, slot_map, n_top); };
-		std::string why = layout(0xffffffffu);
+		const std::string why = mirt_host::build_records(own.data(), static_cast<uint32_t>(own.size()), bvh_prims, n_spheres, recs, &depth, slot_map);
 		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "%s BVH rejected: %s", caller_tree ? "caller's" : "internal", why.c_str());
-		// a tree too large for the LDS staging budget: breadth-first for the staged block only, treelets below it (bvh_layout.hpp)
-		{
-			const uint32_t n_all = static_cast<uint32_t>(recs.size() / 16);
-			std::vector<uint32_t> probe;
-			const bool half_ok = c->allow_half && mirt_host::build_half_records(recs, probe);
-			const uint32_t rec_bytes = half_ok ? 32u : 64u, budget = stage_budget(half_ok, half_ok && n_all <= 65535);
-			if (c->tune_treelets && static_cast<uint64_t>(n_all) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u > budget) {
-				why = layout(budget / rec_bytes);
-				if (!why.empty()) return fail(c, MIRT_ERR_ARG, "BVH layout: %s", why.c_str());
-			}
-		}
 		n_recs = static_cast<uint32_t>(recs.size() / 16);
 		half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
 		if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs))) return r;
@@ -756,7 +745,8 @@ int mirt_load_accumulator(mirt_ctx* c, const float* src, int src_is_device, uint
 	c->deferred = 0;                                                                   // overwritten below
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
-	if (n) HIP_TRY(c, hipMemcpy(c->accumulator.ptr, src, n * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	if (n && src != c->accumulator.ptr)                                                // src == the slab itself (filled in place by mirt_group_gather): only `accumulations` changes
+		HIP_TRY(c, hipMemcpy(c->accumulator.ptr, src, n * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 	c->accumulations = accumulations;
 	return MIRT_OK;
 }
@@ -851,7 +841,7 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	HIP_TRY(c, hipMemcpy(cn, &n32, 4, hipMemcpyHostToDevice));                 // all n rays in segment 0 of the closest queue: slot = ray number
 	StreamBuf in{};
 	in.px = d; in.py = d + n; in.pz = d + 2 * n; in.dx = d + 3 * n; in.dy = d + 4 * n; in.dz = d + 5 * n;
-	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk;
 	DevCounters* scratch_ctr = nullptr;
 	HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
@@ -887,7 +877,7 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	const uint32_t n32 = static_cast<uint32_t>(n);
 	HIP_TRY(c, hipMemcpy(cn + kQueueWords, &n32, 4, hipMemcpyHostToDevice));   // all n rays in segment 0 of the shadow queue
 	HIP_TRY(c, hipMemset(ctr.ptr, 0, sizeof(DevCounters)));
-	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh;
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk;
 	ShadowBuf sh{}; sh.px = d; sh.py = d + n; sh.pz = d + 2 * n; sh.dx = d + 3 * n; sh.dy = d + 4 * n; sh.dz = d + 5 * n; sh.tfar = d + 6 * n;
 	uint32_t* misc = cn + 2 * kQueueWords;
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };

@@ -3,7 +3,8 @@
 // (Resize -> [Accumulate, Render] per frame) through mirt_host.hpp, and writes the resolved frame as a PFM
 // (the reference's F5 screenshot is stbi_write_hdr of the same RGBA buffer, flipped vertically: Image.cpp:71-74).
 //
-//   mirt_headless --scene default9|furnace|bvh_test|synthetic:N [--size WxH] [--spp N | --frames N] [--bounces B] [--buckets K] [--brute] [--out f.pfm]
+//   mirt_headless --scene default9|furnace|bvh_test|synthetic:N [--size WxH] [--spp N | --frames N] [--bounces B] [--buckets K] [--brute] [--devices 0,1,..] [--out f.pfm]
+// --devices: the GPUs the one Renderer object uses (tile rows split over them inside the library, one RCCL gather per frame read).
 // --frames N is the UI loop itself (Application.cpp:373-380): N frames of { Accumulate(); Render(); }; the report lists the frames on
 // which Render() produced output (every `buckets`-th, Renderer.hpp:437) and a hash of the last frame shown.
 #include "mirt_host.hpp"
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
 	uint32_t w = 512, h = 512, spp = 10, n = 0;
 	RendererPolicy policy;
 	float ambient = 0.0f;
+	std::vector<int> devices = { 0 };
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
 		auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -127,6 +129,7 @@ int main(int argc, char** argv) {
 		else if (a == "--ambient") ambient = static_cast<float>(std::atof(next()));
 		else if (a == "--brute") policy.use_bvh = false;
 		else if (a == "--out") out = next();
+		else if (a == "--devices") { devices.clear(); for (const char* p = next(); *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } if (devices.empty()) return 2; }
 		else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
 	}
 	try {
@@ -138,7 +141,7 @@ int main(int argc, char** argv) {
 		else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
 		scene.RebuildAcceleration();                                   // Application.cpp:233-234
 
-		Renderer renderer{ scene, policy };
+		Renderer renderer{ scene, policy, devices };
 		// pad the viewport to the tile requirement like UIRender does (Application.cpp:365-372)
 		const uint32_t t = static_cast<uint32_t>(Renderer::RequiredTiling());
 		w = (w + t - 1) & ~(t - 1); h = (h + t - 1) & ~(t - 1);
@@ -157,18 +160,16 @@ int main(int argc, char** argv) {
 		const mirt_counters c = renderer.counters();
 
 		// FNV-1a over the raw accumulator words: lets a test compare this C++ host against the Python host bit for bit
-		size_t nf = 0; mirt_accumulator_floats(renderer.handle(), &nf);
-		std::vector<float> acc(nf);
-		mirt_read_accumulator(renderer.handle(), acc.data());
+		const std::vector<float> acc = renderer.accumulator();
 		const uint64_t hsh = fnv1a(acc);
 		const uint64_t frame_hsh = have_frame ? fnv1a(renderer.GetFrame()) : 0ull;
 
 		std::printf("{\"scene\": \"%s\", \"spheres\": %zu, \"nodes\": %zu, \"lights\": %zu, \"width\": %u, \"height\": %u, \"accumulations\": %u, "
 		            "\"rays\": %llu, \"shadow_rays\": %llu, \"terminated\": %llu, \"dropped\": %llu, \"seconds\": %.6f, \"mray_per_s\": %.3f, "
-		            "\"accumulator_fnv1a\": \"%016llx\", \"frame_ready\": %s, \"frames_due\": [%s], \"last_frame_fnv1a\": \"%016llx\"}\n",
+		            "\"accumulator_fnv1a\": \"%016llx\", \"frame_ready\": %s, \"frames_due\": [%s], \"last_frame_fnv1a\": \"%016llx\", \"gpus\": %zu, \"gather_ms\": %.3f}\n",
 		            scene_name.c_str(), scene.geometry.size(), scene.acceleration_structure.nodes.size(), scene.lighting_acceleration.prims.size(), w, h,
 		            renderer.accumulations(), (unsigned long long)c.rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.terminated,
-		            (unsigned long long)c.dropped, sec, c.rays / sec / 1e6, (unsigned long long)hsh, have_frame ? "true" : "false", frames_due.c_str(), (unsigned long long)frame_hsh);
+		            (unsigned long long)c.dropped, sec, c.rays / sec / 1e6, (unsigned long long)hsh, have_frame ? "true" : "false", frames_due.c_str(), (unsigned long long)frame_hsh, devices.size(), renderer.gather_ms());
 		if (!out.empty() && have_frame && !write_pfm(out, renderer.GetFrame(), w, h)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "mirt_headless: %s\n", e.what());

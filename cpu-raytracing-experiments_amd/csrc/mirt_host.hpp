@@ -122,54 +122,63 @@ class Renderer {
 public:
 	static constexpr size_t RequiredTiling() { return MIRT_TILE_ROOT; }    // Renderer.hpp:36
 
-	explicit Renderer(const Scene& scene_ref, RendererPolicy policy = {}, int device = 0) : scene(scene_ref) {
-		if (mirt_create(device, &ctx_) != MIRT_OK) throw std::runtime_error(std::string("mirt_create: ") + mirt_last_error(nullptr));
+	// One renderer object, as in the reference (Application.cpp:514) — on one GPU or on several of the node: `devices` lists the HIP
+	// ordinals; the library splits the tile rows over them and gathers the accumulator with one RCCL exchange (mirt.h, mirt_group_*).
+	explicit Renderer(const Scene& scene_ref, RendererPolicy policy = {}, std::vector<int> devices = { 0 }) : scene(scene_ref) {
+		if (mirt_group_create(devices.data(), static_cast<int>(devices.size()), &group_) != MIRT_OK) throw std::runtime_error(std::string("mirt_group_create: ") + mirt_group_last_error(nullptr));
 		mirt_policy p{};
 		p.max_bounces = policy.max_bounces; p.buckets = policy.buckets; p.mis = policy.mis; p.use_bvh = policy.use_bvh; p.reference_tree = policy.reference_tree; p.gpu_build = policy.gpu_build;
-		if (mirt_set_policy(ctx_, &p) < 0) {                                  // no destructor runs for a constructor that throws: release the context here
-			const std::string why = std::string("mirt_set_policy: ") + mirt_last_error(ctx_);
-			mirt_destroy(ctx_); ctx_ = nullptr;
+		if (mirt_group_set_policy(group_, &p) < 0) {                           // no destructor runs for a constructor that throws: release the group here
+			const std::string why = std::string("mirt_group_set_policy: ") + mirt_group_last_error(group_);
+			mirt_group_destroy(group_); group_ = nullptr;
 			throw std::runtime_error(why);
 		}
 	}
-	~Renderer() { if (ctx_) mirt_destroy(ctx_); }
+	~Renderer() { if (group_) mirt_group_destroy(group_); }
 	Renderer(const Renderer&) = delete;
 	Renderer& operator=(const Renderer&) = delete;
 
 	// The reference reads `scene` live; a copy in HBM has to be told about edits (Application.cpp:508-510).
 	void SceneChanged() {
 		const auto& s = scene;
-		check(mirt_set_scene(ctx_, s.geometry.data(), s.acceleration_structure.prims.data(), static_cast<uint32_t>(s.geometry.size()),
-		                     s.acceleration_structure.nodes.data(), static_cast<uint32_t>(s.acceleration_structure.nodes.size()),
-		                     s.material.data(), static_cast<uint32_t>(s.material.size()),
-		                     s.lighting_acceleration.prims.data(), static_cast<uint32_t>(s.lighting_acceleration.prims.size()),
-		                     s.sky.ambient_color, s.sky.hdri_data.data(), static_cast<uint32_t>(s.sky.hdri_width), static_cast<uint32_t>(s.sky.hdri_height)),
-		      "mirt_set_scene");
+		check(mirt_group_set_scene(group_, s.geometry.data(), s.acceleration_structure.prims.data(), static_cast<uint32_t>(s.geometry.size()),
+		                           s.acceleration_structure.nodes.data(), static_cast<uint32_t>(s.acceleration_structure.nodes.size()),
+		                           s.material.data(), static_cast<uint32_t>(s.material.size()),
+		                           s.lighting_acceleration.prims.data(), static_cast<uint32_t>(s.lighting_acceleration.prims.size()),
+		                           s.sky.ambient_color, s.sky.hdri_data.data(), static_cast<uint32_t>(s.sky.hdri_width), static_cast<uint32_t>(s.sky.hdri_height)),
+		      "mirt_group_set_scene");
 		CameraChanged();
 	}
 	void CameraChanged() {
 		const Camera& c = scene.camera;
-		check(mirt_set_camera(ctx_, &c.pos.x, &c.orient.x, c.half_width, c.half_height, c.z, c.exp), "mirt_set_camera");
+		check(mirt_group_set_camera(group_, &c.pos.x, &c.orient.x, c.half_width, c.half_height, c.z, c.exp), "mirt_group_set_camera");
 	}
 	void Resize(uint32_t new_width, uint32_t new_height) {                 // Renderer.hpp:53-63
 		width = new_width; height = new_height;
 		framebuffer.assign(static_cast<size_t>(width) * height * 4, 0.0f);
-		check(mirt_resize(ctx_, width, height), "mirt_resize");
+		check(mirt_group_resize(group_, width, height), "mirt_group_resize");
 	}
-	void ResetAccumulator() { check(mirt_reset(ctx_), "mirt_reset"); }    // Renderer.hpp:64-67
-	// Renderer.hpp:73-434.  Asynchronous: Render() / counters() / the destructor wait for the GPU; called once per frame the library
+	void ResetAccumulator() { check(mirt_group_reset(group_), "mirt_group_reset"); }    // Renderer.hpp:64-67
+	// Renderer.hpp:73-434.  Asynchronous: Render() / counters() / the destructor wait for the GPUs; called once per frame the library
 	// still batches the frames between two Render()s that are due (mirt.h, mirt_accumulate_async).
-	void Accumulate(uint32_t n_calls = 1) { check(mirt_accumulate_async(ctx_, n_calls), "mirt_accumulate_async"); }
-	void Synchronize() { check(mirt_synchronize(ctx_), "mirt_synchronize"); }
+	void Accumulate(uint32_t n_calls = 1) { check(mirt_group_accumulate_async(group_, n_calls), "mirt_group_accumulate_async"); }
+	void Synchronize() { check(mirt_group_synchronize(group_), "mirt_group_synchronize"); }
 	bool Render() {                                                        // Renderer.hpp:436-478; false = frame unchanged (:437)
-		const int rc = mirt_render(ctx_, framebuffer.data());
-		check(rc, "mirt_render");
+		const int rc = mirt_group_render(group_, framebuffer.data());
+		check(rc, "mirt_group_render");
 		return rc == MIRT_OK;
 	}
 	const std::vector<float>& GetFrame() const { return framebuffer; }     // RGBA f32 rows, row 0 = y 0 (Renderer.hpp:40,68)
-	uint32_t accumulations() const { uint32_t a = 0; mirt_get_accumulations(ctx_, &a); return a; }
-	mirt_counters counters() { mirt_counters c{}; check(mirt_get_counters(ctx_, &c), "mirt_get_counters"); return c; }
-	mirt_ctx* handle() { return ctx_; }
+	uint32_t accumulations() const { uint32_t a = 0; mirt_group_get_accumulations(group_, &a); return a; }
+	mirt_counters counters() { mirt_counters c{}; check(mirt_group_get_counters(group_, &c), "mirt_group_get_counters"); return c; }
+	std::vector<float> accumulator() {                                     // the whole image's AccumulationTile slab (Renderer.hpp:43-46)
+		size_t n = 0; mirt_group_accumulator_floats(group_, &n);
+		std::vector<float> acc(n);
+		check(mirt_group_read_accumulator(group_, acc.data()), "mirt_group_read_accumulator");
+		return acc;
+	}
+	double gather_ms() const { double ms = 0; mirt_group_last_gather_ms(group_, &ms); return ms; }
+	mirt_group* handle() { return group_; }
 
 	const Scene& scene;
 	std::vector<float> framebuffer;
@@ -177,9 +186,9 @@ public:
 
 private:
 	void check(int rc, const char* what) const {
-		if (rc < 0) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(ctx_));
+		if (rc < 0) throw std::runtime_error(std::string(what) + ": " + mirt_group_last_error(group_));
 	}
-	mirt_ctx* ctx_ = nullptr;
+	mirt_group* group_ = nullptr;
 };
 
 } // namespace mirt

@@ -188,6 +188,47 @@ int mirt_get_kernel_times(mirt_ctx* ctx, mirt_kernel_times* out, int reset);
 /* HIP stream the context launches on (hipStream_t), for callers that time with their own events. */
 int mirt_get_stream(mirt_ctx* ctx, void** hip_stream);
 
+/* ---- multi-GPU: the same renderer on n devices of one node ------------------------------------------------------
+ * The reference host is ONE object, `Renderer<> renderer{scene}` (Application.cpp:514), whose Accumulate() is a parallel_for over
+ * the tiles (Renderer.hpp:75).  A group is that object on n GPUs, driven by one host thread of one process: one context per
+ * device with the whole scene and an interleaved share of the tile rows (member i: rows i, i+n, ...; mirt_set_tile_rows), no
+ * exchange while rendering, and ONE gather of the accumulator slabs to devices[0] — RCCL point-to-point over xGMI (librccl is loaded
+ * on first use) — with a device-side un-interleave into the full-image AccumulationTile layout, where Render() resolves the whole
+ * frame.  Results equal the single-context ones bit for bit (random draws are keyed on the global LaunchIndex, Renderer.hpp:107).
+ * Entries mirror their mirt_* namesakes; errors: mirt_group_last_error.  devices[] may name one device more than once (rehearsal on
+ * a one-GPU box: slabs are then exchanged with device copies, RCCL needs distinct devices).
+ * (One process PER GPU — torch.distributed / MPI ranks — uses plain contexts with mirt_set_tile_rows + mirt_accumulator_device instead.) */
+typedef struct mirt_group mirt_group;
+int mirt_group_create(const int* devices, int n, mirt_group** out);
+int mirt_group_destroy(mirt_group* group);
+const char* mirt_group_last_error(const mirt_group* group);       /* NULL: of the failed mirt_group_create / selftest */
+int mirt_group_size(const mirt_group* group, int* n);
+int mirt_group_member(mirt_group* group, int index, mirt_ctx** ctx);   /* borrowed: counters, kernel times, debug entry points */
+int mirt_group_set_scene(mirt_group* group,
+                         const mirt_sphere* geometry, const mirt_sphere* bvh_prims, uint32_t n_spheres,
+                         const mirt_bvh_node* nodes, uint32_t n_nodes,
+                         const mirt_material* materials, uint32_t n_materials,
+                         const int32_t* lights, uint32_t n_lights,
+                         const float ambient_color[3], const float* hdri_rgba, uint32_t hdri_w, uint32_t hdri_h);
+int mirt_group_set_camera(mirt_group* group, const float pos[3], const float orient_xyzw[4], float half_width, float half_height, float z, float exposure);
+int mirt_group_set_policy(mirt_group* group, const mirt_policy* policy);
+int mirt_group_resize(mirt_group* group, uint32_t width, uint32_t height);      /* Renderer::Resize + the tile-row split */
+int mirt_group_reset(mirt_group* group);                                         /* Renderer::ResetAccumulator */
+int mirt_group_accumulate(mirt_group* group, uint32_t n_calls);                  /* n x Renderer::Accumulate on every device, then waits */
+int mirt_group_accumulate_async(mirt_group* group, uint32_t n_calls);
+int mirt_group_synchronize(mirt_group* group);
+int mirt_group_get_accumulations(const mirt_group* group, uint32_t* accumulations);
+int mirt_group_get_counters(mirt_group* group, mirt_counters* out);              /* summed over the members */
+/* The one exchange: slabs -> devices[0] (ncclSend / ncclRecv per peer, rccl.h:700,722), un-interleaved there.  Implied by the two
+ * reads below; a no-op for one member or when nothing was accumulated since the last gather. */
+int mirt_group_gather(mirt_group* group);
+int mirt_group_last_gather_ms(const mirt_group* group, double* ms);              /* device time of the last gather incl. un-interleave */
+int mirt_group_accumulator_floats(const mirt_group* group, size_t* n_floats);    /* of the whole image */
+int mirt_group_read_accumulator(mirt_group* group, float* host_dst);             /* whole image, [tile][bucket][r,g,b][256] in LaunchIndex order */
+int mirt_group_render(mirt_group* group, float* rgba_host);                      /* Renderer::Render of the whole frame; MIRT_NOT_READY as mirt_render */
+/* Diagnostic: one-device RCCL communicator on `device`, n_floats sent to itself through a grouped ncclSend / ncclRecv. */
+int mirt_group_rccl_selftest(int device, size_t n_floats);
+
 /* ---- stage-level entry points (parity tests of single kernels) -------------------------------------
  * SoA planes: p_xyz / dir_xyz hold x[n], y[n], z[n] back to back. */
 /* RAY GENERATION, Renderer.hpp:113-127 for Accumulate() number `accumulations`; ray order tile*256 + ID over local tiles. */

@@ -678,6 +678,52 @@ def test_cfg5_policy_16_buckets_17_bounces(mirt):
     r.close()
 
 
+@pytest.mark.parametrize("scene_name,w,h,n_members,spp,mb", [("default9", 160, 96, 3, 10, 16), ("S1000a", 128, 80, 2, 5, 5), ("S1000a", 96, 80, 4, 5, 5)])
+def test_group_in_the_library_reproduces_the_single_renderer(mirt, scene_name, w, h, n_members, spp, mb):
+    """mirt_group_*: one renderer object on n devices — scene replicated, tile rows interleaved, ONE gather to the first device,
+    device-side un-interleave, Render() of the whole frame there.  Members sharing this box's one GPU exchange their slabs with
+    device copies (RCCL needs distinct devices; its calls are covered by test_rccl_selftest); everything else is the multi-GPU
+    path.  Accumulator and frame must equal the single context's and the oracle's bit for bit (80 rows = 5 tile rows: uneven split)."""
+    sc = make_scene(mirt, scene_name)
+    o = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+    g = mirt.GroupRenderer(sc, devices=[0] * n_members, max_bounces=mb, use_bvh=True); g.Resize(w, h)
+    assert not g.Render()                                  # nothing accumulated yet
+    g.Accumulate(spp - 1); g.Accumulate(1)
+    assert g.accumulations == spp
+    assert_same(g.accumulator(), o.accumulator(), f"group of {n_members}: gathered accumulator vs oracle")
+    assert g.Render(); assert_same(g.GetFrame(), o.Render(), "group frame vs oracle")
+    c = g.counters()
+    assert c["rays"] == o.counters()["rays"] and c["terminated"] + c["dropped"] == spp * (w // 16) * (h // 16) * 256
+    assert g.gather_ms() > 0
+    # a second frame after more accumulations: the gather is repeated, not reused
+    g.Accumulate(5); o.Accumulate(5)
+    assert g.Render(); assert_same(g.GetFrame(), o.Render(), "group frame after more accumulations")
+    g.ResetAccumulator(); assert g.accumulations == 0 and not g.accumulator().any()
+    g.close()
+    one = mirt.GroupRenderer(sc, devices=[0], max_bounces=mb, use_bvh=True); one.Resize(w, h); one.Accumulate(spp)
+    o1 = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o1.Resize(w, h); o1.Accumulate(spp)
+    assert_same(one.accumulator(), o1.accumulator(), "group of one")
+    one.close()
+
+
+def test_rccl_selftest(mirt):
+    """The RCCL calls mirt_group_gather makes between distinct devices (dlopen of librccl, ncclCommInitAll, grouped ncclSend /
+    ncclRecv on a HIP stream), exercised on this box's one GPU by sending 4 MB to itself."""
+    mirt.rccl_selftest(0, 1 << 20)
+
+
+def test_cpp_host_on_a_group(mirt):
+    """mirt_headless --devices 0,0: the C++ Renderer mirror drives a two-member group through mirt.h alone; same golden accumulator."""
+    import json
+    import subprocess
+    exe = os.path.join(mirt.CSRC, "mirt_headless")
+    g = np.load(os.path.join(GOLDEN, "default9_64x64_10spp_b16.npz"))
+    out = subprocess.run([exe, "--scene", "default9", "--size", "64x64", "--spp", "10", "--devices", "0,0"], check=True, capture_output=True, text=True).stdout
+    rep = json.loads(out)
+    assert rep["gpus"] == 2 and rep["accumulations"] == 10 and rep["rays"] == int(g["rays"]) and rep["frame_ready"]
+    assert rep["accumulator_fnv1a"] == _fnv1a(g["accumulator"]) and rep["last_frame_fnv1a"] == _fnv1a(g["frame"])
+
+
 def test_accumulator_device_view_for_rccl(mirt):
     """The multi-GPU gather wraps the context's accumulator slab as a torch tensor without a copy."""
     import torch
