@@ -99,6 +99,8 @@ struct mirt_ctx {
 	size_t frame_host_bytes = 0;
 	DeviceBuffer counters;           // DevCounters
 	std::vector<PipeSlot> slots;     // batches in flight (policy.streams)
+	uint64_t planned_for = 0;        // local pixel count batch_mem_cap was planned for (0 = plan again)
+	uint32_t batch_mem_cap = 64;     // accumulations per batch the device memory allows (lowered by ensure_streams when the plan does not fit)
 	uint32_t capacity = 0;           // rays per stream plane (= kSegs * seg_cap)
 	uint32_t seg_cap = 0;            // slots per queue segment
 	uint32_t arena_bounces = 0;
@@ -123,18 +125,28 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 }
 #define HIP_TRY(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
 
-// Accumulations traced together as one batch.  A trace launch ends in a ~0.2 ms tail while its longest rays finish, so
-// launches want to be large: by default a batch carries about 32 M primary rays (cfg2: 32 accumulations of 1024^2),
-// at most kMaxBatch (the path id keeps the slot in 7 bits).
+// Accumulations traced together as one batch (path id = (slot << 24) | pixel; the slot keeps bits 30 and 31 free, hence <= 64).
+// Every launch of a batch ends in a tail while its longest rays finish and starts with the staging of the tree top, so
+// launches want to be LARGE — and 288 GB of HBM is there to be used for ray streams (188 B per ray and batch in flight).
+// Measured on one MI355X (Mray/s; accumulations per batch x batches in flight on separate HIP streams):
+//   cfg4 4096^2 S(100000):  5 x 3: 4919   8 x 1: 5435   16 x 1: 5726   32 x 1: 5838   16 x 2: 5013
+//   one eighth of cfg4:     16 x 3: 4367  32 x 3: 4981  64 x 3: 5103   64 x 1: 5498
+//   cfg3 1920x1088 S(10000): 16 x 3: 5378  32 x 3: 5753  64 x 3: 5700  64 x 1: 6354
+//   cfg2 1024^2 S(1000):    32 x 3: 7510  64 x 3: 8011  64 x 1: 7654
+// Hence: aim at 512 M primary rays per batch (at most 64 accumulations, at most what the free device memory holds), and keep
+// ONE batch in flight once a batch carries 96 M primary rays or more — launches that fill the chip for milliseconds gain
+// nothing from sharing it with another stream's kernels and lose to the interleaving — three below that (other batches fill the tails).
 constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestFull)
-constexpr uint64_t kBatchRays = 32ull << 20;
+constexpr uint64_t kBatchRays = 512ull << 20;
+constexpr uint64_t kSerialRays = 96ull << 20;
+constexpr size_t kStreamPlanes = 2 * 14 + 2 + 17;      // two ray streams, hit (tfar, prim), shadow stream: 4-byte planes per ray of capacity
+uint32_t batch_floor(const mirt_ctx* c) { return std::max<uint32_t>(std::min<uint32_t>(c->policy.buckets, 5u), 1u); }   // the reference's natural group: five calls, five buckets
 uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
 	if (n_pix == 0) return 1;
-	// large images: still at least the reference's natural group of 5 (84 M rays at 4096^2 — deep trees have longer tails)
-	const uint64_t b = std::max<uint64_t>((kBatchRays + n_pix / 2) / n_pix, std::min<uint32_t>(c->policy.buckets, 5u));
-	return static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(b, 1), kMaxBatch));
+	const uint64_t b = std::max<uint64_t>((kBatchRays + n_pix / 2) / n_pix, batch_floor(c));
+	return static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(b, kMaxBatch), std::max<uint32_t>(c->batch_mem_cap, 1u)));
 }
 // Paths add straight into the accumulator only when a batch cannot touch a (pixel, bucket) word twice and no other
 // batch is in flight; otherwise every batch adds into its own contribution buffer, merged in accumulation order.
@@ -177,13 +189,33 @@ hipError_t sync_all(mirt_ctx* c) {
 constexpr uint32_t kQueueWords = kSegs * kSegPitch;     // one ray queue's counters
 size_t counts_words(uint32_t nb) { return static_cast<size_t>(2 * nb + 2) * kQueueWords + static_cast<size_t>(nb) * 4 + 8; }
 constexpr uint32_t kFatCapacity = 1u << 16;   // rays per list and launch that may take the brute-force detour (a few per million qualify)
-uint32_t wanted_slots(const mirt_ctx* c) { const uint32_t s = c->policy.streams ? c->policy.streams : 3u; return s > 8u ? 8u : s; }
+uint32_t wanted_slots(const mirt_ctx* c) {
+	if (c->policy.streams) return std::min<uint32_t>(c->policy.streams, 8u);
+	return static_cast<uint64_t>(c->n_tiles) * kTileSize * batch_limit(c) >= kSerialRays ? 1u : 3u;
+}
+// Device bytes of the batches in flight for the current plan (ray streams + contribution buffers).
+uint64_t streams_bytes(const mirt_ctx* c) {
+	const uint64_t rays = static_cast<uint64_t>(c->n_tiles) * kTileSize * batch_limit(c);
+	return wanted_slots(c) * (rays * 4u * kStreamPlanes + (uses_contrib(c, wanted_slots(c)) ? rays * 12u : 0u));
+}
 
 // Carve each slot's frame-wide ray streams out of one allocation.
 int ensure_streams(mirt_ctx* c) {
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
+	if (n_pix * batch_limit(c) == 0) return MIRT_OK;
+	if (!c->policy.max_batch && c->planned_for != n_pix) {
+		// automatic batch size: as large as kBatchRays asks, but within 80 % of the device memory that is free once this context's
+		// own streams are released (other contexts and processes may share the device)
+		HIP_TRY(c, sync_all(c));
+		for (PipeSlot& sl : c->slots) { sl.arena.release(); sl.contrib.release(); }
+		c->capacity = 0;
+		c->batch_mem_cap = kMaxBatch;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			while (batch_limit(c) > batch_floor(c) && streams_bytes(c) > free_b / 5 * 4) c->batch_mem_cap = std::max(batch_limit(c) / 2, batch_floor(c));
+		c->planned_for = n_pix;
+	}
 	const uint64_t cap64 = n_pix * batch_limit(c);
-	if (cap64 == 0) return MIRT_OK;
 	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
 	if (cap64 + kSegs * kShadeBlock > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
 	// a ray queue is kSegs segments of seg_cap slots (kernels.hpp "ray queues"): a plane holds kSegs * seg_cap entries
@@ -210,11 +242,21 @@ int ensure_streams(mirt_ctx* c) {
 		HIP_TRY(c, hipEventCreateWithFlags(&sl.merged, hipEventDisableTiming));
 		c->slots.push_back(sl);
 	}
-	const size_t planes = 2 * 14 + 2 + 17;           // two ray streams, hit (tfar, prim), shadow stream
+	const size_t planes = kStreamPlanes;
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	for (PipeSlot& sl : c->slots) {
 		sl.in_use = false;
-		HIP_TRY(c, sl.arena.ensure(planes * plane_bytes));
+		if (const hipError_t e = sl.arena.ensure(planes * plane_bytes); e != hipSuccess) {
+			// not enough device memory after all (someone else took it meanwhile): halve the automatic batch and plan again
+			(void)hipGetLastError();
+			if (e == hipErrorOutOfMemory && !c->policy.max_batch && batch_limit(c) > batch_floor(c)) {
+				for (PipeSlot& other : c->slots) { other.arena.release(); other.contrib.release(); }
+				c->capacity = 0;
+				c->batch_mem_cap = std::max(batch_limit(c) / 2, batch_floor(c));
+				return ensure_streams(c);
+			}
+			return fail(c, MIRT_ERR_HIP, "ray streams (%zu bytes per batch in flight): %s", planes * plane_bytes, hipGetErrorString(e));
+		}
 		HIP_TRY(c, sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)));
 		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 		if (contrib) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
@@ -625,6 +667,7 @@ int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
 	HIP_TRY(c, sync_all(c));
 	const bool realloc_acc = p->buckets != c->policy.buckets;
 	c->policy = *p;
+	c->planned_for = 0;                                                                // batch size / batches in flight are planned again at the next launch
 	if (realloc_acc && c->n_tiles) { int r = alloc_accumulator(c); if (r) return r; }
 	return MIRT_OK;
 }

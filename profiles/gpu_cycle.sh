@@ -20,8 +20,9 @@ except Exception as e:
     print('bench parse failed', e)
 PY
 for V in "$@"; do
-  CFG=${V%%:*}; ENVS=${V#*:}
-  step "ab $V" 300 env $(echo $ENVS | tr ',' ' ') python bench.py --config $CFG --steps 3 --warmup 1 --no-pmc --no-cpu-baseline > gpurun_out/ab.json 2> gpurun_out/ab.err
+  # V = config:ENV1=a,ENV2=b[:extra bench.py arguments separated by commas]
+  CFG=$(echo "$V" | cut -d: -f1); ENVS=$(echo "$V" | cut -d: -f2); EXTRA=$(echo "$V" | cut -s -d: -f3 | tr ',' ' ')
+  step "ab $V" 300 env $(echo $ENVS | tr ',' ' ') python bench.py --config $CFG --steps 3 --warmup 1 --no-pmc --no-cpu-baseline $EXTRA > gpurun_out/ab.json 2> gpurun_out/ab.err
   python -c "
 import json
 try:
