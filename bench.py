@@ -37,12 +37,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue roof: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz max clock — one wave64 VALU instruction per 4 cycles per SIMD.
-# (The chip's 157.3 TFLOP/s f32 vector peak = 64 FLOP/clk/SIMD is reached only by the PACKED form v_pk_fma_f32, two f32 lanes-ops per
-# lane and instruction: cdna_hip_programming.md §3 "Rate".  This path is per-lane scalar arithmetic — box and sphere tests with
-# different operands in every lane, compares, selects, integer hashing — none of which has a packed encoding, so its roof is the
-# unpacked issue rate.)  Unit: 10^12 lane-instructions per second; a wave64 instruction counts 64 lane slots whatever its exec mask.
-VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12
+# VALU roof.  The resource is the SIMD's vector ALU issue: 256 CUs x 4 SIMDs = 1024 pipes, one issue slot per quad-cycle each.
+#   achieved = VALU-issuing quad-cycles x 4 per second, from this run's PMC child pass: SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2 (the
+#              quad-cycles in which two VALU instructions issued together hold two instructions) per traced ray x rays traced per second;
+#   peak     = 1024 SIMDs x 2.4 GHz max clock; frac = share of all SIMD-cycles in which the VALU was issuing for this kernel.
+# Why not lane-instructions against the 78.6 Tlane-inst/s behind the 157.3 TFLOP/s vector peak (kept as `lane_instructions`): only
+# plain f32 add / mul / fma reach that rate.  Measured with 8 waves per SIMD (profiles/experiments/valu_rates.hip, profiles/r02/valu_rates.txt):
+# v_fma_f32 2.6, v_add_f32 2.5, v_fma_mix_f32 4.4, v_med3 / v_max3 / v_max / v_lshl_add 4.3, v_cmp + v_cndmask 3.3 each, v_sqrt_f32 8.2
+# cycles per wave64 instruction.  k_trace's traversal step is ~80 % such half-rate work (compares, selects, min / max / med3,
+# binary16-decoding FMAs, integer address arithmetic): the all-FMA rate is not reachable by a traversal, the issue slots are.
+VALU_PEAK_GCYC = 256 * 4 * 2.4            # 10^9 SIMD-cycles per second
+VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
+MIX_COUNTERS = "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"
 SQ_COUNTERS = "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY"
 
 
@@ -122,8 +128,9 @@ def collect_pmc(args, log):
     if sq is None:
         return None
     out["sq"], out["child"] = sq
-    for name in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):   # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes; GRBM: the clock the chip held
-        r = run_pmc_pass(name, args, log)
+    # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes; GRBM: the clock the chip held; then the VALU instruction mix
+    for name, counters in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("mix", MIX_COUNTERS)):
+        r = run_pmc_pass(counters, args, log)
         out[name] = r[0] if r else None
     log(f"pmc passes took {time.perf_counter() - t0:.1f}s")
     return out
@@ -313,8 +320,8 @@ def main():
             trace_s = tr["ms"] * 1e-3
             traced = counts["rays"] + counts["shadow_rays"]
             ab = algorithmic_bytes(counts)
-            roofline = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_TLANE, "unit": "Tlane-inst/s", "frac": None, "traffic": None,
-                        "peak_definition": "256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: one unpacked wave64 VALU instruction per 4 cycles per SIMD (the 157.3 TFLOP/s vector peak needs v_pk_fma_f32, which per-lane box/sphere tests, compares and selects cannot use); a wave64 instruction counts 64 lane slots",
+            roofline = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "G VALU-issuing SIMD-cycles/s", "frac": None, "traffic": None,
+                        "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz max clock: a VALU instruction issuing on every SIMD in every quad-cycle; achieved = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) per second",
                         "launches": tr["launches"], "avg_launch_ms": tr["ms"] / tr["launches"],
                         "measured_with": f"HIP events on the launch stream, second live pass of {aux} step(s) with one batch in flight",
                         "traced_rays_per_launch": traced / tr["launches"],
@@ -328,23 +335,35 @@ def main():
                 q, ch = pmc["sq"]["trace"], pmc["child"]
                 ch_traced = ch["rays"] + ch["shadow_rays"]
                 valu_per_ray = q["SQ_INSTS_VALU"] / ch_traced
-                ach = valu_per_ray * traced * 64.0 / trace_s / 1e12
-                roofline.update(achieved=ach, frac=ach / VALU_PEAK_TLANE,
-                                valu_wave_instructions_per_traced_ray=valu_per_ray, salu_per_valu=q["SQ_INSTS_SALU"] / q["SQ_INSTS_VALU"],
-                                lane_utilisation=q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0),
-                                useful_frac=ach / VALU_PEAK_TLANE * q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0),
+                mix = (pmc.get("mix") or {}).get("trace")
+                busy_per_ray = ach = None
+                if mix and mix.get("SQ_INSTS_VALU"):
+                    # issue quad-cycles = instructions - the quad-cycles that held two of them; scaled to this pass's instruction count per ray
+                    busy_per_ray = 4.0 * (1.0 - mix["SQ_ACTIVE_INST_VALU2"] / mix["SQ_INSTS_VALU"]) * valu_per_ray
+                    ach = busy_per_ray * traced / trace_s / 1e9
+                lane_ach = valu_per_ray * traced * 64.0 / trace_s / 1e12
+                lane_util = q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0)
+                roofline.update(achieved=ach, frac=(ach / VALU_PEAK_GCYC) if ach else None,
+                                valu_issue_cycles_per_traced_ray=busy_per_ray, valu_wave_instructions_per_traced_ray=valu_per_ray,
+                                simd_cycles_per_valu_instruction=(VALU_PEAK_GCYC * 1e9 * trace_s) / (valu_per_ray * traced),
+                                instruction_mix=({k.replace("SQ_INSTS_VALU_", "").lower(): v / mix["SQ_INSTS_VALU"] for k, v in mix.items() if k.startswith("SQ_INSTS_VALU_")} if mix else None),
+                                dual_issue_share=(2.0 * mix["SQ_ACTIVE_INST_VALU2"] / mix["SQ_INSTS_VALU"]) if mix else None,
+                                salu_per_valu=q["SQ_INSTS_SALU"] / q["SQ_INSTS_VALU"],
+                                lane_utilisation=lane_util, useful_frac=(ach / VALU_PEAK_GCYC * lane_util) if ach else None,
                                 wait_share=q["SQ_WAIT_ANY"] / max(q["SQ_WAVE_CYCLES"], 1.0),
+                                lane_instructions={"achieved": lane_ach, "peak": VALU_PEAK_TLANE, "unit": "Tlane-inst/s", "frac": lane_ach / VALU_PEAK_TLANE,
+                                                   "note": "against the all-FMA issue rate (one wave64 instruction per 2 cycles per SIMD = the 157.3 TFLOP/s vector peak / 2 flop); "
+                                                           "k_trace's mix is ~80 % half-rate instructions (4 cycles), see profiles/r02/valu_rates.txt"},
                                 pmc={"source": pmc["command"], "batch": ch["batch"], "launches": q["launches"], "k_trace_ms_under_pmc": q["us"] / 1e3,
-                                     "traced_rays": ch_traced, "SQ_INSTS_VALU": q["SQ_INSTS_VALU"]},
-                                note="achieved = VALU wave-instructions per traced ray (SQ_INSTS_VALU of the k_trace dispatches of one batch, this run's rocprofv3 --pmc child pass) "
-                                     "x rays traced in the HIP-event pass x 64 lanes / k_trace time of that pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
-                                     "useful_frac = frac x lane_utilisation")
+                                     "traced_rays": ch_traced, "SQ_INSTS_VALU": q["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU2_per_inst": (mix["SQ_ACTIVE_INST_VALU2"] / mix["SQ_INSTS_VALU"]) if mix else None},
+                                note="achieved = VALU issue quad-cycles x 4 per traced ray (k_trace dispatches of one batch, this run's rocprofv3 --pmc child passes) x rays traced per "
+                                     "second in the HIP-event pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_frac = frac x lane_utilisation")
                 gr = pmc.get("GRBM_GUI_ACTIVE")
                 if gr and "trace" in gr and gr["trace"]["us"] > 0:
                     # MI355X_MICROARCH.md "DVFS give-back": effective clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
                     ghz = gr["trace"]["GRBM_GUI_ACTIVE"] / 8.0 / (gr["trace"]["us"] * 1e-6) / 1e9
                     roofline["clock_GHz_during_k_trace"] = ghz
-                    roofline["frac_at_that_clock"] = ach / (256 * 4 * 16 * ghz * 1e9 / 1e12)
+                    roofline["frac_at_that_clock"] = (ach / (256 * 4 * ghz)) if ach else None
                 f, w_ = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
                 if f and w_ and "trace" in f and "trace" in w_:
                     # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact; both in KB
