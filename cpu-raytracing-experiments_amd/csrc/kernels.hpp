@@ -61,7 +61,8 @@ struct StreamBuf {
 	float *px, *py, *pz, *dx, *dy, *dz;
 	float *tr, *tg, *tb;        // throughput
 	float *rr, *rg, *rb;        // radiance
-	float *pdf;
+	                            // (`pdf` has no plane: Closure::pdf of the sampled direction is (1/pi) max(0, dir.z) of the WORLD-space dir
+	                            //  (Q8, Renderer.hpp:386,401), a function of the stored direction, recomputed by the bounce that needs it)
 	uint32_t* path;             // (batch slot << 24) | local pixel index (tile_local*256 + ID); stands in for pixelID + seed[]
 };
 // RayStream<>::ShadowStream, DataStreams.hpp:113-126, plus the deferred-add operands.  A record is 32 B for the common case
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		uint32_t path = 0;
 		f3 P{0, 0, 0}, ndir{0, 0, 0}, L{0, 0, 0}, srad{0, 0, 0}, E{0, 0, 0};
 		f3 R{0.0f, 0.0f, 0.0f}, thr{1.0f, 1.0f, 1.0f};
-		float npdf = 0.0f, light_distance = 0.0f;
+		float light_distance = 0.0f;
 		if (FIRST ? is_hit : threadIdx.x < n_hits) {
 			const uint32_t i = FIRST ? my_slot : hit_list[threadIdx.x];
 			f3 D;
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			if (!FIRST) {
 				R = { in.rr[i], in.rg[i], in.rb[i] };
 				thr = { in.tr[i], in.tg[i], in.tb[i] };
-				pdf_in = in.pdf[i];
+				pdf_in = MIRT_INV_PI * max_sel(0.0f, D.z);                        // out->pdf of the bounce that sampled D (Q8), bit for bit
 			}
 			const int32_t prim = prim_in[i];
 			{
@@ -1028,7 +1029,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 						const float inv = 1.0f / max_sel(MIRT_FLT_EPSILON, 1.0f - q);
 						thr = { thr.x * inv, thr.y * inv, thr.z * inv };
 						ndir = to_world(T, sd);
-						npdf = MIRT_INV_PI * max_sel(0.0f, ndir.z);                 // Q8: pdf of the world-space direction
 						survive = true;
 					}
 				}
@@ -1045,7 +1045,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 			out.px[slot] = P.x; out.py[slot] = P.y; out.pz[slot] = P.z;
 			out.dx[slot] = ndir.x; out.dy[slot] = ndir.y; out.dz[slot] = ndir.z;
 			out.tr[slot] = thr.x; out.tg[slot] = thr.y; out.tb[slot] = thr.z;
-			out.pdf[slot] = npdf;
 			out.path[slot] = path;
 		}
 		if (has_shadow) {

@@ -127,7 +127,7 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 
 // Accumulations traced together as one batch (path id = (slot << 24) | pixel; the slot keeps bits 30 and 31 free, hence <= 64).
 // Every launch of a batch ends in a tail while its longest rays finish and starts with the staging of the tree top, so
-// launches want to be LARGE — and 288 GB of HBM is there to be used for ray streams (188 B per ray and batch in flight).
+// launches want to be LARGE — and 288 GB of HBM is there to be used for ray streams (180 B per ray and batch in flight).
 // Measured on one MI355X (Mray/s; accumulations per batch x batches in flight on separate HIP streams):
 //   cfg4 4096^2 S(100000):  5 x 3: 4919   8 x 1: 5435   16 x 1: 5726   32 x 1: 5838   16 x 2: 5013
 //   one eighth of cfg4:     16 x 3: 4367  32 x 3: 4981  64 x 3: 5103   64 x 1: 5498
@@ -139,7 +139,7 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestFull)
 constexpr uint64_t kBatchRays = 512ull << 20;
 constexpr uint64_t kSerialRays = 96ull << 20;
-constexpr size_t kStreamPlanes = 2 * 14 + 2 + 17;      // two ray streams, hit (tfar, prim), shadow stream: 4-byte planes per ray of capacity
+constexpr size_t kStreamPlanes = 2 * 13 + 2 + 17;      // two ray streams, hit (tfar, prim), shadow stream: 4-byte planes per ray of capacity
 uint32_t batch_floor(const mirt_ctx* c) { return std::max<uint32_t>(std::min<uint32_t>(c->policy.buckets, 5u), 1u); }   // the reference's natural group: five calls, five buckets
 uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
@@ -268,7 +268,7 @@ int ensure_streams(mirt_ctx* c) {
 			s.dx = (float*)take(); s.dy = (float*)take(); s.dz = (float*)take();
 			s.tr = (float*)take(); s.tg = (float*)take(); s.tb = (float*)take();
 			s.rr = (float*)take(); s.rg = (float*)take(); s.rb = (float*)take();
-			s.pdf = (float*)take(); s.path = (uint32_t*)take();
+			s.path = (uint32_t*)take();
 		}
 		sl.hit_tfar = (float*)take(); sl.hit_prim = (int32_t*)take();
 		ShadowBuf& h = sl.shadow_buf;

@@ -1,12 +1,20 @@
 #!/bin/bash
-# Collects the round's judged artefacts on the GPU box into gpurun_out/final/ (copied to profiles/rNN/ afterwards).
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf gpurun_out/final; mkdir -p gpurun_out/final
-timeout -k 10 400 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; echo "bench rc=$?"; tail -1 gpurun_out/final/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt_serial -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > gpurun_out/final/bench_serial_rocprof.json 2>/dev/null; echo "kt_serial $?"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt_pipe -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-counts > gpurun_out/final/bench_pipe_rocprof.json 2>/dev/null; echo "kt_pipe $?"
-B="python3 bench.py --steps 1 --warmup 0 --spp 32 --streams 1 --no-cpu-baseline --no-counts"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pmc_fetch -- $B > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pmc_write -- $B > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d gpurun_out/final/p1 -- $B > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --output-format csv -d gpurun_out/final/p2 -- $B > /dev/null 2>&1
-echo "pmc done"; cat gpurun_out/final/bench.json
+# Collects the round's judged artefacts on the GPU box into gpurun_out/final/ (copied to profiles/rNN/ by store_round.py).
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rm -rf gpurun_out/final; mkdir -p gpurun_out/final; F=gpurun_out/final
+step() { name=$1; shift; timeout -k 10 "$@"; rc=$?; echo "[$name] rc=$rc" >&2; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] timed out: stopping" >&2; exit 1; fi; return 0; }
+# 1. the default bench line (cfg4, with its in-run PMC child passes) and the other BASELINE configs
+step bench 600 python bench.py > $F/bench.json 2> $F/bench.err; tail -2 $F/bench.err
+for C in cfg2 cfg3 cfg5; do step bench_$C 400 python bench.py --config $C --no-cpu-baseline > $F/bench_$C.json 2> $F/bench_$C.err; done
+# 2. rocprofv3 --kernel-trace --stats of the same command (per-kernel average durations; HIP-event figures must agree)
+for C in cfg4 cfg3; do
+  step kt_$C 600 rocprofv3 --kernel-trace --stats --output-format csv -d $F/kt_$C -- python3 bench.py --config $C --steps 2 --warmup 1 --no-pmc --no-cpu-baseline > $F/bench_rocprof_$C.json 2> $F/kt_$C.err
+done
+# 3. SQ counters per dispatch of one batch and the VALU instruction mix, cfg4 and cfg3
+for C in cfg4 cfg3; do
+  step pmc_$C 700 bash profiles/pmc_profile.sh $C > $F/pmc_by_dispatch_$C.txt 2> $F/pmc_$C.err; cp -r gpurun_out/pmc_$C $F/ 2>/dev/null
+  step mix_$C 400 bash profiles/pmc_mix.sh $C > $F/pmc_mix_$C.txt 2> $F/mix_$C.err
+done
+# 4. one rank's share of the strong-scaled cfg4 image (what each GPU of an 8-GPU run does)
+step share 400 python profiles/experiments/rank_share.py 8 > $F/rank_share_8.txt 2> $F/share.err
+step rates 100 ./profiles/experiments/valu_rates > $F/valu_rates_raw.txt 2>&1
+echo "collected"; head -c 600 $F/bench.json

@@ -1,35 +1,27 @@
 #!/usr/bin/env python3
-"""Copies gpurun_out/final/ (see collect_round.sh) into profiles/rNN/ as small summaries."""
-import collections, csv, glob, json, os, shutil, subprocess, sys
-dst = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01"
+"""Copies gpurun_out/final/ (see collect_round.sh) into profiles/rNN/ as small text summaries."""
+import csv, glob, json, os, shutil, sys
+dst = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02"
 src = "gpurun_out/final"
 os.makedirs(dst, exist_ok=True)
-shutil.copy(f"{src}/bench.json", f"{dst}/bench.json")
-shutil.copy(max(glob.glob(f"{src}/kt_serial/*/*_kernel_stats.csv"), key=os.path.getmtime), f"{dst}/kernel_stats_streams1.csv")
-shutil.copy(max(glob.glob(f"{src}/kt_pipe/*/*_kernel_stats.csv"), key=os.path.getmtime), f"{dst}/kernel_stats_streams3.csv")
-shutil.copy(f"{src}/bench_serial_rocprof.json", f"{dst}/bench_under_rocprof_streams1.json")
-out = {"note": "rocprofv3 --pmc passes (separate runs, one counter each) of `python3 bench.py --steps 1 --warmup 0 --spp 32 --streams 1 --no-cpu-baseline --no-counts` "
-               "(one batch of 32 accumulations, 1024x1024, S(1000): the launch sizes of the default bench run). sum_KB are KB summed over the launches as rocprofv3 reports them; "
-               "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024/launches, the gfx950 correction of MI355X_MICROARCH.md §HBM (FETCH_SIZE reports half of wide coalesced reads).", "kernels": {}}
-agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-for name in ("pmc_fetch", "pmc_write"):
-    f = max(glob.glob(f"{src}/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-        a = agg[k][row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
-for k, v in agg.items():
-    if "mirt" not in k: continue
-    e = {c: {"launches": a[0], "sum_KB": a[1]} for c, a in v.items()}
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        e["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE"][1] + v["WRITE_SIZE"][1]) * 1024 / v["FETCH_SIZE"][0]
-    out["kernels"][k] = e
-json.dump(out, open(f"{dst}/pmc_hbm_traffic.json", "w"), indent=1)
-with open(f"{dst}/pmc_sq_by_dispatch.txt", "w") as f:
-    f.write("# rocprofv3 --pmc SQ counters per k_trace dispatch (one batch, streams=1); lane-util = SQ_THREAD_CYCLES_VALU / (64*SQ_ACTIVE_INST_VALU)\n")
-    f.write(subprocess.run([sys.executable, "profiles/pmc_by_dispatch.py", src], capture_output=True, text=True).stdout)
-print(open(f"{dst}/pmc_sq_by_dispatch.txt").read())
+for name in ("bench.json", "bench_cfg2.json", "bench_cfg3.json", "bench_cfg5.json", "pmc_by_dispatch_cfg4.txt", "pmc_by_dispatch_cfg3.txt", "pmc_mix_cfg4.txt", "pmc_mix_cfg3.txt", "rank_share_8.txt"):
+    if os.path.exists(f"{src}/{name}"):
+        shutil.copy(f"{src}/{name}", f"{dst}/{name}")
+for cfg in ("cfg4", "cfg3"):
+    files = glob.glob(f"{src}/kt_{cfg}/*/*_kernel_stats.csv")
+    if files:
+        shutil.copy(max(files, key=os.path.getmtime), f"{dst}/kernel_stats_{cfg}.csv")
+    if os.path.exists(f"{src}/bench_rocprof_{cfg}.json"):
+        shutil.copy(f"{src}/bench_rocprof_{cfg}.json", f"{dst}/bench_under_rocprof_{cfg}.json")
 b = json.load(open(f"{dst}/bench.json")); r = b["roofline"]
-print("value %.1f Mray/s  ms/step %.2f  frac %.3f  avg_launch_ms %.4f  cpu %.2f" % (b["value"], b["ms_per_step"], r["frac"], r["avg_launch_ms"], b["cpu_baseline"]["value"]))
-for fn in ("kernel_stats_streams1.csv",):
-    for row in csv.DictReader(open(f"{dst}/{fn}")):
-        if "mirt" in row["Name"]: print("   %-26s calls %5s avg %9.1f us" % (row["Name"].split("(")[0].replace("void ", "")[:26], row["Calls"], float(row["AverageNs"]) / 1e3))
+print("value %.1f Mray/s  ms/step %.2f  valu frac %.3f (at %.2f GHz: %.3f)  lane util %.2f  avg k_trace launch %.3f ms  cpu %.2f Mray/s" % (
+    b["value"], b["ms_per_step"], r["frac"], r.get("clock_GHz_during_k_trace") or 0, r.get("frac_at_that_clock") or 0, r["lane_utilisation"], r["avg_launch_ms"], b["cpu_baseline"]["value"]))
+for cfg in ("cfg4", "cfg3"):
+    fn = f"{dst}/kernel_stats_{cfg}.csv"
+    if not os.path.exists(fn): continue
+    print(cfg, "rocprofv3 --kernel-trace --stats:")
+    for row in csv.DictReader(open(fn)):
+        if "mirt" in row["Name"]:
+            print("   %-34s calls %5s avg %10.1f us  total %8.1f ms" % (row["Name"].split("(")[0].replace("void ", "")[:34], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e6))
+    rb = json.load(open(f"{dst}/bench_under_rocprof_{cfg}.json"))
+    print("   bench under rocprof: HIP-event avg k_trace launch %.1f us" % (rb["roofline"]["avg_launch_ms"] * 1e3))
