@@ -237,13 +237,12 @@ def main():
     count = n_rows * h_tiles
 
     r = make_renderer(mirt, cfg, local_rank, profile=False, streams=args.streams, max_batch=args.max_batch)
-    n_streams = args.streams or 3
     r.Resize(width, height)
     if world > 1:
         r.SetTileRows(first_row, row_stride)
     spp, K, W = args.spp, args.steps, args.warmup
-    batch = r.get_policy()["max_batch"]
-    log(f"{args.config}: {width}x{height}, S({cfg['n']}), {spp} accumulations/step, batches of {batch}, {count} of {tiles} tiles on this rank")
+    batch, n_streams = r.get_policy()["max_batch"], r.get_policy()["streams"]     # the values in effect (0 = automatic: see batch planning in mirt_capi.hip)
+    log(f"{args.config}: {width}x{height}, S({cfg['n']}), {spp} accumulations/step, batches of {batch} x {n_streams} in flight, {count} of {tiles} tiles on this rank")
 
     def sync_all():
         r.Synchronize()
