@@ -153,6 +153,75 @@ MIRT_DI f3 sample_direction_to_sphere(f3 Wc, float sinThetaMax2, float center_di
 	         wcX.y * Ll.x + wcY.y * Ll.y + Wc.y * Ll.z,
 	         wcX.z * Ll.x + wcY.z * Ll.y + Wc.z * Ll.z };
 }
+// ---- GGX closure, function level (DataStreams.hpp:184-219, Sampling.hpp:85-91,102-104,254-309) --------------
+// The reference's path with this closure does not build (`#define BRDF 0`; `gloss_decay_table` of Renderer.hpp:212 is declared
+// nowhere) and Closure<GGX>::pdf returns 0 ("TODO"), so these functions are NOT wired into k_shade; they are the defined part of the
+// closure, checked bit for bit against the oracle through mirt_debug_math (fn 8, 9).
+MIRT_DI float mix_glm(float x, float y, float a) { return x * (1.0f - a) + y * a; }           // glm::mix
+MIRT_DI float clamp_std(float v, float lo, float hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
+MIRT_DI void disk(float t, float s, float& x, float& y) {                                       // Sampling.hpp:85-91,102-104
+	float cos_phi, sin_phi; fast_sincos(s * MIRT_TWO_PI, sin_phi, cos_phi);
+	const float rho = __builtin_sqrtf(t);
+	x = rho * cos_phi; y = rho * sin_phi;
+}
+MIRT_DI f3 distribution_visible_normals(f3 Vlocal, float alpha, float u, float v) {             // :254-270
+	const f3 V = normalize3(f3{ alpha * Vlocal.x, alpha * Vlocal.y, Vlocal.z });
+	float sx, sy; disk(u, v, sx, sy);
+	const float t = 1.0f - sx * sx;
+	sy = mix_glm(__builtin_sqrtf(t), sy, V.z * 0.5f + 0.5f);
+	f3 X, Y; orthonormal_basis(V, X, Y);
+	const float k = __builtin_sqrtf(max_sel(0.0f, t - sy * sy));
+	const f3 H{ (X.x * sx + Y.x * sy) + V.x * k, (X.y * sx + Y.y * sy) + V.y * k, (X.z * sx + Y.z * sy) + V.z * k };
+	return normalize3(f3{ alpha * H.x, alpha * H.y, max_sel(0.0f, H.z) });
+}
+MIRT_DI float pow5(float x) { float t = x * x; t *= t; return x * t; }                          // :272
+MIRT_DI f3 Fresnel(f3 F0, float HdotV) {                                                        // :273-275
+	const float a = pow5(clamp_std(1.0f - HdotV, 0.0f, 1.0f));
+	return { mix_glm(F0.x, 1.0f, a), mix_glm(F0.y, 1.0f, a), mix_glm(F0.z, 1.0f, a) };
+}
+MIRT_DI float GGX_D(float alpha2, float NdotH2) { const float temp = (1.0f + (alpha2 - 1.0f) * NdotH2); return alpha2 / (MIRT_PI * temp * temp); }   // :278-281
+MIRT_DI float smith_g2_lagarde(float alpha2, float NdotL, float NdotV) {                        // :287-291
+	const float a = NdotV * __builtin_sqrtf(alpha2 + NdotL * (NdotL - alpha2 * NdotL));
+	const float b = NdotL * __builtin_sqrtf(alpha2 + NdotV * (NdotV - alpha2 * NdotV));
+	return 0.5f / (a + b);
+}
+MIRT_DI f3 microfacet_brdf(f3 F0, float alpha, float NdotV, float NdotL, float NdotH, float HdotV) {   // :293-296
+	const float alpha2 = alpha * alpha;
+	const f3 F = Fresnel(F0, HdotV);
+	const float k = NdotL * GGX_D(max_sel(0.00001f, alpha2), NdotH * NdotH) * smith_g2_lagarde(alpha2, NdotL, NdotV);
+	return { F.x * k, F.y * k, F.z * k };
+}
+MIRT_DI float G1_GGX(float alpha2, float NdotS2) { return 2.0f / (1.0f + __builtin_sqrtf(((alpha2 * (1.0f - NdotS2)) + NdotS2) / NdotS2)); }   // :297-299
+MIRT_DI float smith_g2_over_g1(float alpha2, float NdotL, float NdotV) {                        // :301-305
+	const float G1V = G1_GGX(alpha2, NdotV * NdotV), G1L = G1_GGX(alpha2, NdotL * NdotL);
+	return G1L / (G1V + G1L - G1V * G1L);
+}
+MIRT_DI f3 vndf_estimator(f3 F0, float alpha, float NdotV, float NdotL, float HdotV) {          // :307-309
+	const f3 F = Fresnel(F0, HdotV);
+	const float k = smith_g2_over_g1(alpha * alpha, NdotL, NdotV);
+	return { F.x * k, F.y * k, F.z * k };
+}
+MIRT_DI f3 ggx_eval(f3 F0, float alpha, f3 Llocal, f3 Vlocal) {                                 // Closure<GGX>::eval, DataStreams.hpp:189-195
+	const float NdotL = max_sel(0.0f, Llocal.z), NdotV = max_sel(0.0f, Vlocal.z);
+	const f3 Hn = normalize3(f3{ Llocal.x + Vlocal.x, Llocal.y + Vlocal.y, Llocal.z + Vlocal.z });
+	const float NdotH = max_sel(0.0f, Hn.z), HdotV = max_sel(0.0f, dot3(Hn, Vlocal));
+	return microfacet_brdf(F0, alpha, NdotV, NdotL, NdotH, HdotV);
+}
+MIRT_DI void ggx_sample(f3 F0, float alpha, f3 Vlocal, float u0, float u1, f3& dir, f3& estimator) {   // Closure<GGX>::sample, DataStreams.hpp:200-218
+	const float NdotV = max_sel(0.0f, Vlocal.z);
+	float HdotV;
+	if (alpha == 0.0f) { dir = f3{ -Vlocal.x, -Vlocal.y, Vlocal.z }; HdotV = NdotV; }
+	else {
+		const f3 Hl = distribution_visible_normals(Vlocal, alpha, u0, u1);
+		HdotV = dot3(Hl, Vlocal);
+		const float k = 2.0f * HdotV;
+		dir = f3{ k * Hl.x - Vlocal.x, k * Hl.y - Vlocal.y, k * Hl.z - Vlocal.z };
+		HdotV = max_sel(0.0f, HdotV);
+	}
+	const float NdotL = max_sel(0.0f, dir.z);
+	estimator = vndf_estimator(F0, alpha, NdotV, NdotL, HdotV);
+}
+
 MIRT_DI float powerHeuristic(float f, float g) { float f2 = f * f; return f2 / max_sel(1e-6f, f2 + g * g); }   // :241-244
 MIRT_DI float powerHeuristic_over_f(float f, float g) { return f / max_sel(1e-6f, f * f + g * g); }            // :245-247
 MIRT_DI float median3(float a, float b, float c) { return max_sel(min_sel(a, b), min_sel(max_sel(a, b), c)); } // :8-12

@@ -24,7 +24,7 @@
 namespace mirt {
 
 constexpr uint32_t kBlock = 256;
-constexpr uint32_t kShadeBlock = 512;           // shade: ~80 VGPRs = 24 waves per CU = three 8-wave workgroups (1024-thread workgroups: one per CU, every barrier stalls the CU)
+constexpr uint32_t kShadeBlock = 512;           // shade: 73-79 VGPRs = 24 waves per CU = three 8-wave workgroups (forced to 64 VGPRs for a fourth: 15-20 spills, 92 -> 109 ms per cfg4 step; 1024-thread workgroups: one per CU, every barrier stalls the CU)
 constexpr uint32_t kTraceBlock = 1024;          // trace kernels: one workgroup per CU stages the BVH into LDS once per launch
 constexpr uint32_t kLdsStack = 16;              // traversal-stack entries per lane kept in LDS (deeper ones spill to scratch)
 constexpr uint32_t kLdsStackWide = 12;          // ... with binary16 records but u32 entries (> 65535 records): 48 KB, so that two workgroups still share a CU
@@ -1155,6 +1155,15 @@ __global__ __launch_bounds__(kBlock) void k_debug_math(int fn, uint32_t n, const
 			uint32_t s2 = s;
 			out[3 * n + i] = rand_unit_float(s);
 			out[4 * n + i] = __uint_as_float(rand_bounded_int(s2, __float_as_uint(in[2 * n + i])));
+		} break;
+		case 8: {   // Closure<GGX>::eval: in F0(3), alpha, L(3), V(3) -> out 3
+			const f3 r = ggx_eval(f3{ in[i], in[n + i], in[2 * n + i] }, in[3 * n + i], f3{ in[4 * n + i], in[5 * n + i], in[6 * n + i] }, f3{ in[7 * n + i], in[8 * n + i], in[9 * n + i] });
+			out[i] = r.x; out[n + i] = r.y; out[2 * n + i] = r.z;
+		} break;
+		case 9: {   // Closure<GGX>::sample: in F0(3), alpha, V(3), u0, u1 -> out dir(3), estimator(3)
+			f3 d, e;
+			ggx_sample(f3{ in[i], in[n + i], in[2 * n + i] }, in[3 * n + i], f3{ in[4 * n + i], in[5 * n + i], in[6 * n + i] }, in[7 * n + i], in[8 * n + i], d, e);
+			out[i] = d.x; out[n + i] = d.y; out[2 * n + i] = d.z; out[3 * n + i] = e.x; out[4 * n + i] = e.y; out[5 * n + i] = e.z;
 		} break;
 		default: break;
 		}

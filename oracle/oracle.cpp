@@ -249,6 +249,84 @@ static inline v3 sample_direction_to_sphere(v3 Wc, float sinThetaMax2, float cen
 	         wcX.y * Ll.x + wcY.y * Ll.y + Wc.y * Ll.z,
 	         wcX.z * Ll.x + wcY.z * Ll.y + Wc.z * Ll.z };
 }
+// ---- GGX closure (DataStreams.hpp:184-219, Sampling.hpp:102-104,254-309) — §8f rank 4, FUNCTION LEVEL ONLY ----------------------
+// The reference compiles this path out (`#define BRDF 0`, Renderer.hpp:70): with BRDF 1 it does not build (`gloss_decay_table`,
+// Renderer.hpp:212, is declared nowhere) and Closure<GGX>::pdf returns 0 (DataStreams.hpp:198, "TODO").  What IS defined — eval and
+// sample of the closure and the functions under them — is restated here so that the device versions can be checked bit for bit.
+// glm: mix(x, y, a) = x * (1 - a) + y * a; vec3 * float and vec3 + vec3 componentwise, left to right.
+static inline float glm_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+static inline float std_clamp(float v, float lo, float hi) { return (v < lo) ? lo : (hi < v) ? hi : v; }
+static inline void polar_to_cartesian(float phi_over_2pi, float rho, float* x, float* y) {      // Sampling.hpp:85-91
+	float cos_phi, sin_phi; fast_sincos(phi_over_2pi * kTwoPi, &sin_phi, &cos_phi);
+	*x = rho * cos_phi; *y = rho * sin_phi;
+}
+static inline void disk(float t, float s, float* x, float* y) { polar_to_cartesian(s, sqrtf(t), x, y); }   // :102-104
+static inline v3 distribution_visible_normals(v3 Vlocal, float alpha, float u, float v) {        // :254-270
+	v3 V = normalize3(v3{ alpha * Vlocal.x, alpha * Vlocal.y, Vlocal.z });
+	float sx, sy; disk(u, v, &sx, &sy);
+	const float t = 1.0f - sx * sx;
+	sy = glm_mix(sqrtf(t), sy, V.z * 0.5f + 0.5f);
+	v3 X, Y; orthonormal_basis(V, &X, &Y);
+	const float k = sqrtf(std_max(0.0f, t - sy * sy));
+	v3 H{ (X.x * sx + Y.x * sy) + V.x * k, (X.y * sx + Y.y * sy) + V.y * k, (X.z * sx + Y.z * sy) + V.z * k };
+	return normalize3(v3{ alpha * H.x, alpha * H.y, std_max(0.0f, H.z) });
+}
+static inline float pow5(float x) { float t = x * x; t *= t; return x * t; }                       // :272
+static inline v3 Fresnel(v3 F0, float HdotV) {                                                    // :273-275
+	const float a = pow5(std_clamp(1.0f - HdotV, 0.0f, 1.0f));
+	return { glm_mix(F0.x, 1.0f, a), glm_mix(F0.y, 1.0f, a), glm_mix(F0.z, 1.0f, a) };
+}
+static inline float GGX_D(float alpha2, float NdotH2) {                                            // :278-281
+	float temp = (1.0f + (alpha2 - 1.0f) * NdotH2);
+	return alpha2 / (kPi * temp * temp);
+}
+static inline float Smith_G2_Height_Correlated_GGX_Lagarde(float alpha2, float NdotL, float NdotV) {   // :287-291
+	float a = NdotV * sqrtf(alpha2 + NdotL * (NdotL - alpha2 * NdotL));
+	float b = NdotL * sqrtf(alpha2 + NdotV * (NdotV - alpha2 * NdotV));
+	return 0.5f / (a + b);
+}
+static inline v3 microfacet_brdf(v3 F0, float alpha, float NdotV, float NdotL, float NdotH, float HdotV) {   // :293-296
+	const float alpha2 = alpha * alpha;
+	const v3 F = Fresnel(F0, HdotV);
+	const float k = NdotL * GGX_D(std_max(0.00001f, alpha2), NdotH * NdotH) * Smith_G2_Height_Correlated_GGX_Lagarde(alpha2, NdotL, NdotV);
+	return { F.x * k, F.y * k, F.z * k };
+}
+static inline float G1_GGX(float alpha2, float NdotS2) { return 2.0f / (1.0f + sqrtf(((alpha2 * (1.0f - NdotS2)) + NdotS2) / NdotS2)); }   // :297-299
+static inline float Smith_G2_Over_G1_Height_Correlated(float alpha2, float NdotL, float NdotV) {  // :301-305
+	float G1V = G1_GGX(alpha2, NdotV * NdotV);
+	float G1L = G1_GGX(alpha2, NdotL * NdotL);
+	return G1L / (G1V + G1L - G1V * G1L);
+}
+static inline v3 vndf_estimator(v3 F0, float alpha, float NdotV, float NdotL, float HdotV) {      // :307-309
+	const v3 F = Fresnel(F0, HdotV);
+	const float k = Smith_G2_Over_G1_Height_Correlated(alpha * alpha, NdotL, NdotV);
+	return { F.x * k, F.y * k, F.z * k };
+}
+static inline v3 ggx_eval(v3 F0, float alpha, v3 Llocal, v3 Vlocal) {                            // Closure<GGX>::eval, DataStreams.hpp:189-195
+	float NdotL = std_max(0.0f, Llocal.z);
+	float NdotV = std_max(0.0f, Vlocal.z);
+	const v3 Hn = normalize3(v3{ Llocal.x + Vlocal.x, Llocal.y + Vlocal.y, Llocal.z + Vlocal.z });
+	float NdotH = std_max(0.0f, Hn.z);
+	float HdotV = std_max(0.0f, dot3(Hn, Vlocal));
+	return microfacet_brdf(F0, alpha, NdotV, NdotL, NdotH, HdotV);
+}
+static inline void ggx_sample(v3 F0, float alpha, v3 Vlocal, float u0, float u1, v3* dir, v3* estimator) {   // Closure<GGX>::sample, DataStreams.hpp:200-218
+	float NdotV = std_max(0.0f, Vlocal.z);
+	float HdotV;
+	if (alpha == 0.0f) {
+		*dir = v3{ -Vlocal.x, -Vlocal.y, Vlocal.z };
+		HdotV = NdotV;
+	} else {
+		v3 Hlocal = distribution_visible_normals(Vlocal, alpha, u0, u1);
+		HdotV = dot3(Hlocal, Vlocal);
+		const float k = 2.0f * HdotV;
+		*dir = v3{ k * Hlocal.x - Vlocal.x, k * Hlocal.y - Vlocal.y, k * Hlocal.z - Vlocal.z };
+		HdotV = std_max(0.0f, HdotV);
+	}
+	float NdotL = std_max(0.0f, dir->z);
+	*estimator = vndf_estimator(F0, alpha, NdotV, NdotL, HdotV);
+}
+
 static inline float powerHeuristic(float f, float g) { float f2 = f * f; return f2 / std_max(1e-6f, f2 + g * g); } // :241-244
 static inline float powerHeuristic_over_f(float f, float g) { return f / std_max(1e-6f, f * f + g * g); }         // :245-247
 
@@ -1369,6 +1447,13 @@ int orc_debug_path(void* h, uint32_t LaunchIndex, uint32_t px, uint32_t accumula
 }
 
 // ---- unit functions (KATs / per-function fixtures) -------------------------------------
+void orc_ggx_eval(const float* F0, float alpha, const float* L, const float* V, float* out) {
+	const v3 r = ggx_eval(v3{F0[0], F0[1], F0[2]}, alpha, v3{L[0], L[1], L[2]}, v3{V[0], V[1], V[2]}); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_ggx_sample(const float* F0, float alpha, const float* V, float u0, float u1, float* dir_out, float* estimator_out) {
+	v3 d, e; ggx_sample(v3{F0[0], F0[1], F0[2]}, alpha, v3{V[0], V[1], V[2]}, u0, u1, &d, &e);
+	dir_out[0] = d.x; dir_out[1] = d.y; dir_out[2] = d.z; estimator_out[0] = e.x; estimator_out[1] = e.y; estimator_out[2] = e.z;
+}
 uint32_t orc_hash_u32(uint32_t i) { return hash_u32(i); }
 uint32_t orc_hash_2d(uint32_t x, uint32_t y) { return hash_2d(x, y); }
 uint32_t orc_pcg_generate(uint32_t* s) { return pcg_generate(s); }

@@ -72,6 +72,8 @@ def load():
     lib.orc_to_world.argtypes = [vp, vp, vp]
     lib.orc_hemisphere.argtypes = [f, f, vp]
     lib.orc_sample_direction_to_sphere.argtypes = [vp, f, f, f, f, f, vp]
+    lib.orc_ggx_eval.argtypes = [vp, f, vp, vp, vp]
+    lib.orc_ggx_sample.argtypes = [vp, f, vp, f, f, vp, vp]
     lib.orc_median5.argtypes = [f] * 5; lib.orc_median5.restype = f
     lib.orc_tonemap.argtypes = [vp]
     _lib = lib

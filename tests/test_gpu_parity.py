@@ -110,6 +110,39 @@ def test_device_math_bit_exact(mirt, gpu, oracle_lib):
 
 
 # ---- single kernels ------------------------------------------------------------------------------------------------
+def test_ggx_closure_functions_bit_exact(mirt, gpu, oracle_lib):
+    """SURVEY.md §8f rank 4, function level: Closure<GGX>::eval / ::sample (DataStreams.hpp:184-219) and everything under them
+    (Sampling.hpp:254-309) on the device vs the oracle, bit for bit.  The reference's PATH with this closure does not build
+    (`#define BRDF 0`; `gloss_decay_table` is declared nowhere; pdf() returns 0), so the closure is not wired into k_shade."""
+    lib = oracle_lib
+    rng = np.random.default_rng(21)
+    n = 4000
+    def unit_upper(k):
+        v = rng.normal(size=(k, 3)); v[:, 2] = np.abs(v[:, 2]) + 1e-3
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    F0 = rng.uniform(0.02, 1.0, (n, 3)).astype(np.float32)
+    alpha = (rng.uniform(0.0, 1.0, n) ** 2).astype(np.float32); alpha[:8] = [0.0, 1.0, 1e-4, 0.5, 0.0, 1e-3, 0.25, 0.04]
+    L, V = unit_upper(n), unit_upper(n)
+    V[:4] = [(0, 0, 1), (1e-3, 0, 1), (0.6, 0.0, 0.8), (0.0, 0.8, 0.6)]
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32); u[:4] = [(0, 0), (1, 1), (0.5, 0.25), (0.999, 0.001)]
+    inp = np.concatenate([F0.T, alpha[None, :], L.T, V.T]).astype(np.float32)
+    got = gpu.debug_math(8, inp, 3)
+    want = np.zeros((n, 3), dtype=np.float32)
+    for i in range(n):
+        lib.orc_ggx_eval(F0[i].ctypes.data_as(C.c_void_p), float(alpha[i]), L[i].ctypes.data_as(C.c_void_p), V[i].ctypes.data_as(C.c_void_p), want[i].ctypes.data_as(C.c_void_p))
+    assert_same(got.T, want, "Closure<GGX>::eval")
+    assert np.isfinite(want).all() and (want >= 0).all()
+    inp = np.concatenate([F0.T, alpha[None, :], V.T, u.T]).astype(np.float32)
+    got = gpu.debug_math(9, inp, 6)
+    wd, we = np.zeros((n, 3), dtype=np.float32), np.zeros((n, 3), dtype=np.float32)
+    for i in range(n):
+        lib.orc_ggx_sample(F0[i].ctypes.data_as(C.c_void_p), float(alpha[i]), V[i].ctypes.data_as(C.c_void_p), float(u[i, 0]), float(u[i, 1]),
+                           wd[i].ctypes.data_as(C.c_void_p), we[i].ctypes.data_as(C.c_void_p))
+    assert_same(got[:3].T, wd, "Closure<GGX>::sample direction"); assert_same(got[3:].T, we, "Closure<GGX>::sample estimator")
+    mirror = alpha == 0.0                                  # alpha 0: perfect mirror about the normal (DataStreams.hpp:203-209)
+    assert np.array_equal(wd[mirror], V[mirror] * np.float32([-1, -1, 1]))
+
+
 def test_raygen_bit_exact(mirt):
     sc = mirt.scene.default9()
     r = mirt.Renderer(sc, max_bounces=16); r.Resize(96, 64)

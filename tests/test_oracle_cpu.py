@@ -134,6 +134,28 @@ def test_accumulation_is_incremental_and_thread_independent(mirt):
     assert a.accumulations == 0 and not a.accumulator().any()
 
 
+def test_ggx_closure_properties(oracle_lib):
+    """The defined part of the reference's compiled-out GGX closure (DataStreams.hpp:184-219), restated in the oracle: sanity
+    properties that hold by construction — mirror reflection at alpha 0, estimator = Fresnel x G2/G1 within [0, 1] for F0 <= 1,
+    sampled directions of unit length, eval non-negative and finite."""
+    lib = oracle_lib
+    rng = np.random.default_rng(5)
+    f3 = lambda a: np.ascontiguousarray(a, dtype=np.float32)   # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)                # noqa: E731
+    for _ in range(2000):
+        V = rng.normal(size=3); V[2] = abs(V[2]) + 1e-2; V = f3(V / np.linalg.norm(V))
+        L = rng.normal(size=3); L[2] = abs(L[2]) + 1e-2; L = f3(L / np.linalg.norm(L))
+        F0 = f3(rng.uniform(0.02, 1.0, 3)); alpha = float(np.float32(rng.uniform(1e-3, 1.0) ** 2))
+        d, e, ev = f3(np.zeros(3)), f3(np.zeros(3)), f3(np.zeros(3))
+        lib.orc_ggx_sample(p(F0), alpha, p(V), float(rng.uniform()), float(rng.uniform()), p(d), p(e))
+        assert abs(float(np.linalg.norm(d.astype(np.float64))) - 1.0) < 1e-4
+        assert np.all(e >= 0) and np.all(e <= 1.0 + 1e-5)
+        lib.orc_ggx_eval(p(F0), alpha, p(L), p(V), p(ev))
+        assert np.isfinite(ev).all() and np.all(ev >= 0)
+        lib.orc_ggx_sample(p(F0), 0.0, p(V), 0.3, 0.7, p(d), p(e))
+        assert np.array_equal(d, V * np.float32([-1, -1, 1]))
+
+
 def test_tile_list_reproduces_the_full_image_slabs(mirt):
     """Oracle.Resize(w, h, tiles=...) renders only the listed LaunchIndices of the w x h image (the full-size GPU spot
     checks rely on it): their slabs must equal the same tiles of a full render, because every draw depends only on the
