@@ -105,7 +105,7 @@ def run_pmc_pass(counters, args, log):
             name = row["Kernel_Name"]
             if "mirt::k_trace_fat" in name or "mirt::" not in name:
                 continue
-            klass = "trace" if "mirt::k_trace<" in name else "shade" if "mirt::k_shade<" in name else "other"
+            klass = "trace" if ("mirt::k_trace<" in name or "mirt::k_primary_" in name) else "shade" if "mirt::k_shade<" in name else "other"   # k_primary_*: Traverse of the camera rays
             a = agg.setdefault(klass, {"launches": set(), "us": 0.0})
             a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             if row["Dispatch_Id"] not in a["launches"]:

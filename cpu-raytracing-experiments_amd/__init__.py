@@ -35,7 +35,7 @@ class Policy(C.Structure):
     """mirt_policy — RendererPolicy (Renderer.hpp:19-26) + the path's compile-time switches."""
     _fields_ = [("max_bounces", C.c_uint32), ("buckets", C.c_uint32), ("mis", C.c_uint32), ("use_bvh", C.c_uint32),
                 ("count_traffic", C.c_uint32), ("profile", C.c_uint32), ("max_batch", C.c_uint32), ("reference_tree", C.c_uint32),
-                ("streams", C.c_uint32), ("gpu_build", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
+                ("streams", C.c_uint32), ("gpu_build", C.c_uint32), ("trace_primary_rays", C.c_uint32), ("_reserved", C.c_uint32 * 1)]
 
 
 class Counters(C.Structure):
@@ -99,6 +99,7 @@ def load_library():
         "mirt_debug_trace_shadow": [P, C.c_size_t, vp, vp, vp, vp],
         "mirt_debug_math": [P, i32, C.c_size_t, vp, vp],
         "mirt_debug_info": [P, vp],
+        "mirt_debug_primary_lists": [P, vp],
         "mirt_debug_allow_half_boxes": [P, i32],
     }
     G = C.c_void_p
@@ -177,7 +178,7 @@ class Renderer:
 
     def __init__(self, scene: Scene, device: int = 0, max_bounces: int = 16, buckets: int = 5, mis: bool = True,
                  use_bvh: bool = False, count_traffic: bool = False, profile: bool = False, max_batch: int = 0,
-                 allow_half_boxes: bool = True, reference_tree: bool = False, streams: int = 0, gpu_build: bool = False):
+                 allow_half_boxes: bool = True, reference_tree: bool = False, streams: int = 0, gpu_build: bool = False, trace_primary_rays: bool = False):
         self._lib = load_library()
         self._ctx = C.c_void_p()
         rc = self._lib.mirt_create(device, C.byref(self._ctx))
@@ -186,7 +187,7 @@ class Renderer:
         self.scene = scene
         self.width = self.height = 0
         self.framebuffer = None
-        self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), int(profile), max_batch, int(reference_tree), int(streams), int(gpu_build))
+        self.policy = Policy(max_bounces, buckets, int(mis), int(use_bvh), int(count_traffic), int(profile), max_batch, int(reference_tree), int(streams), int(gpu_build), int(trace_primary_rays))
         self._check(self._lib.mirt_set_policy(self._ctx, C.byref(self.policy)))
         self._check(self._lib.mirt_debug_allow_half_boxes(self._ctx, int(allow_half_boxes)))
         self.UpdateScene()
@@ -321,6 +322,12 @@ class Renderer:
         self._check(self._lib.mirt_debug_info(self._ctx, out))
         keys = ("records", "lds_records", "lds_spheres", "depth", "half_boxes", "trace_lds_bytes", "trace_workgroups_per_cu", "cus")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def debug_primary_lists(self) -> list:
+        """hist[n] = pixels whose candidate list holds n spheres (0..8), hist[9] = pixels without a list."""
+        out = (C.c_uint32 * 10)()
+        self._check(self._lib.mirt_debug_primary_lists(self._ctx, out))
+        return [int(v) for v in out]
 
     def stream_handle(self) -> int:
         p = C.c_void_p()

@@ -253,10 +253,10 @@ MIRT_DI void slab_axis(float p, float d, float alpha, float& ia, float& na, floa
 	nb = keep ? -(p * rb) : __builtin_inff();
 	c = (prod < 0.0f) ? __builtin_inff() : -__builtin_inff();
 }
-MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz, float& alpha_out) {
+MIRT_DI RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz, float& alpha_out, float alpha_extra = 0.0f) {
 	const float L2 = (dx * dx + dy * dy) + dz * dz;
 	const float a2 = __builtin_fmaxf(L2 - 1.0f, 0.0f) * 1.0009765625f + 0x1p-19f;
-	const float alpha = __builtin_sqrtf(a2) * 1.0009765625f;
+	const float alpha = __builtin_sqrtf(a2) * 1.0009765625f + alpha_extra;     // alpha_extra: a BUNDLE of rays around this axis (k_primary_cand)
 	alpha_out = alpha;
 	RaySlab s;
 	slab_axis(px, dx, alpha, s.iax, s.nax, s.ibx, s.nbx, s.cx);
@@ -344,18 +344,53 @@ struct TravSpill { uint32_t e[kStack - kLdsStackWide]; };
 // lane would walk it serially (measured: 20-57 ms per launch on a 100k-sphere scene).  They go to a "fat ray" list and
 // k_trace_fat intersects them with every sphere, a whole workgroup per ray — literally the reference's brute-force loop.
 constexpr float kAlphaFat = 0.01f;
-MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar) {     // true = fat ray
+MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar, float alpha_extra = 0.0f) {     // true = fat ray
 	t.px = px; t.py = py; t.pz = pz; t.dx = dx; t.dy = dy; t.dz = dz;
 	float alpha;
-	t.rs = make_slab(px, py, pz, dx, dy, dz, alpha);
+	t.rs = make_slab(px, py, pz, dx, dy, dz, alpha, alpha_extra);
 	t.tfar = tfar; t.prim = -1; t.cur = 0; t.sp = 0;
 	return alpha > kAlphaFat;
 }
 // One step = one 64-B record: slab-test both children against the current tfar, intersect hit leaf children at once,
 // re-check inner children against the shrunken tfar, enter the nearer, push the other (or pop).  Returns true when this
 // ray is finished (stack empty, or ANYHIT occluder found -> occluded = true).
-template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
-MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres) {
+// MODE: kClosest (Traverse), kAnyHit (Traverse_shadow), kCollect (candidate spheres of a pixel's bundle of camera rays, below).
+constexpr int kClosest = 0, kAnyHit = 1, kCollect = 2;
+// kCollect — what the samples of ONE PIXEL can hit.  Within a batch a pixel is sampled up to 64 times with sub-pixel jitter
+// (Renderer.hpp:117-118); all those camera rays leave cam.pos inside a cone of half-angle rho around the ray through the pixel
+// centre.  Traversing that cone once (the same conservative slab test, widened by rho) and listing the spheres it can touch turns
+// the primary traversal of every sample into a few exact sphere tests (k_primary_hits).  The list is complete for the closest hit:
+//   * a sphere some sample reports a hit on at parameter d has its reported hit point within alpha_s d of the sphere and within
+//     rho d of the axis point at d, so its box inflated by (alpha_s + rho) d meets the axis — the cone test with alpha + rho;
+//   * the search is cut at F once a sphere is found that EVERY sample must hit: centre within the silhouette by a margin that
+//     covers the cone's reach and the reference's f32 discriminant error, origin outside.  F bounds every sample's first-hit
+//     distance on it from above, hence every sample's closest-hit distance: a sphere whose box starts beyond F cannot be a closest hit.
+// A pixel whose list would exceed kCandMax entries (silhouettes of many small spheres) is marked and its samples are traced normally.
+constexpr uint32_t kCandMax = 15, kCandStride = 16, kCandOverflow = 0xffffffffu;
+struct Collect { uint32_t* cand; float rho; };      // cand[pixel * kCandStride]: count, then up to kCandMax BVH-order prim indices
+MIRT_DI void collect_leaf(bool on, float4 s, uint32_t prim, uint32_t pix, const Collect& col, Trav& t) {
+	uint32_t cnt = static_cast<uint32_t>(t.prim);
+	if (on & (cnt < kCandMax)) col.cand[static_cast<size_t>(pix) * kCandStride + 1u + cnt] = prim;
+	cnt += on ? 1u : 0u;
+	t.prim = static_cast<int32_t>(cnt);
+	// full cover -> every sample hits this sphere no later than F
+	const f3 oc{ s.x - t.px, s.y - t.py, s.z - t.pz };
+	const float oc2 = dot3(oc, oc), b = dot3(f3{ t.dx, t.dy, t.dz }, oc);
+	const float len = __builtin_sqrtf(oc2);
+	const float reach = __builtin_sqrtf(__builtin_fmaxf(oc2 - b * b, 0.0f)) + col.rho * len;       // farthest a sample ray can pass from the centre
+	// The discriminant every sample is left with after the worst rounding of the reference's f32 evaluation of b^2 - |oc|^2 + r^2
+	// (15 roundings of magnitude 2^-24 |oc|^2, directions that are unit only to 1e-7, and this function's own cancellation in
+	// oc2 - b*b: together < 2^-19.5 |oc|^2; 2^-17 leaves a factor 5).  Positive: the reference reports a hit for every sample, at a
+	// parameter no larger than (b + rho |oc|) - sqrt(slack).
+	const float slack = (s.w - reach * reach) - (0x1p-17f * oc2 + 1e-6f * s.w);
+	const bool cover = on & (b > 0.0f) & (oc2 > s.w * 1.002f) & (slack > 0.0f);
+	const float F = ((b + col.rho * len) - __builtin_sqrtf(__builtin_fmaxf(slack, 0.0f))) * 1.001f + 1e-4f;
+	t.tfar = (cover & (F < t.tfar)) ? F : t.tfar;
+}
+template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
+MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres,
+                       uint32_t pix = 0, const Collect col = Collect{ nullptr, 0.0f }) {
+	constexpr bool ANYHIT = MODE == kAnyHit;
 	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
 	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
 	constexpr uint32_t lstride = kTraceBlock;     // every trace launch uses kTraceBlock threads (a runtime blockDim.x costs a quarter-rate v_mul_lo_u32 per push and per pop)
@@ -424,7 +459,8 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 				if (ALL_LDS || first < sc.lds_spheres) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];
 			}
 			if (COUNT) n_spheres += on ? 1u : 0u;
-			if (ANYHIT) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
+			if (MODE == kAnyHit) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
+			else if (MODE == kCollect) collect_leaf(on, s, first, pix, col, t);
 			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 		}
 	}
@@ -449,7 +485,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		if (sp < lds_entries) next = ST16 ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
 		else next = spill.e[sp - lds_entries];
 	}
-	const bool finished = (ANYHIT & occluded) | (none & !pop);
+	const bool finished = (ANYHIT & occluded) | (none & !pop) | ((MODE == kCollect) & (static_cast<uint32_t>(t.prim) > kCandMax));   // a full list: the pixel falls back to tracing
 	t.sp = sp;
 	t.cur = next;
 	return finished;
@@ -508,9 +544,9 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n,
 //     ray indices of the window and loads + sets up their rays — all as batched, mostly coalesced accesses.  (An earlier
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
-template <bool ANYHIT, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
+template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
-                              LoadRay load_ray, StoreResult store_result) {
+                              LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f }) {
 	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n, sc.chunk_max), true };
 	Trav t;
 	TravSpill spill;
@@ -525,7 +561,10 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 				float px, py, pz, dx, dy, dz, tf;
 				load_ray(got, px, py, pz, dx, dy, dz, tf);
 				ri = got; occluded = false;
-				if (trav_begin(t, px, py, pz, dx, dy, dz, tf)) {
+				if (MODE == kCollect) {
+					if (trav_begin(t, px, py, pz, dx, dy, dz, tf, col.rho)) { t.prim = static_cast<int32_t>(kCandMax + 1u); done = true; }   // a bundle too wide for the tree: the pixel is traced normally
+					else t.prim = 0;                                           // candidates listed so far
+				} else if (trav_begin(t, px, py, pz, dx, dy, dz, tf)) {
 					const uint32_t k = atomicAdd(fat.count, 1u);               // rare: a few rays per million
 					if (k < fat.capacity) { fat.rays[k] = got; ri = kNone; }   // list full -> traverse it after all (correct, only slow)
 				}
@@ -536,7 +575,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		const bool can_refill = work_left;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
 		for (;;) {
-			if (ri != kNone && !done) done = trav_step<ANYHIT, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_nodes, c_spheres);
+			if (ri != kNone && !done) done = trav_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_nodes, c_spheres, ri, col);
 			const unsigned long long running = __ballot(ri != kNone && !done);
 			if (running == 0ull) break;
 			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;
@@ -616,15 +655,20 @@ MIRT_DI uint32_t path_seed(const FrameParams& fp, uint32_t pix) {      // seed[I
 // RAY GENERATION, Renderer.hpp:97-127, for stream index i = slot * n_pix + pix of a batch: path id and direction (the origin
 // is cam.pos).  Bounce 0 has no ray stream in HBM: k_trace<PRIMARY> and k_shade<FIRST> both derive the ray from its index
 // (~90 VALU instructions each, against 28 B written + 52 B read per primary ray).
-MIRT_DI void primary_ray(const FrameParams& fp, uint32_t i, uint32_t& path, float& dx, float& dy, float& dz) {
-	uint32_t pix;
-	const uint32_t slot = udiv_f(i, fp.n_pix, fp.inv_n_pix, pix);
-	const uint32_t tile = global_tile(fp, pix >> 8);
+MIRT_DI void pixel_xy(const FrameParams& fp, uint32_t pix, uint32_t& tile, int32_t& x, int32_t& y) {     // Renderer.hpp:84-88,115-116
+	tile = global_tile(fp, pix >> 8);
 	const uint32_t ID = pix & 255u;
 	uint32_t col;
 	const uint32_t row = udiv_f(tile, fp.h_tiles, fp.inv_h_tiles, col);
-	const int32_t x = static_cast<int32_t>(kTileRoot * col + (ID & 15u));
-	const int32_t y = static_cast<int32_t>(kTileRoot * row + (ID >> 4));
+	x = static_cast<int32_t>(kTileRoot * col + (ID & 15u));
+	y = static_cast<int32_t>(kTileRoot * row + (ID >> 4));
+}
+MIRT_DI void primary_ray(const FrameParams& fp, uint32_t i, uint32_t& path, float& dx, float& dy, float& dz) {
+	uint32_t pix, tile;
+	const uint32_t slot = udiv_f(i, fp.n_pix, fp.inv_n_pix, pix);
+	int32_t x, y;
+	pixel_xy(fp, pix, tile, x, y);
+	const uint32_t ID = pix & 255u;
 	const uint32_t acc = fp.acc_base + slot + 1u;                           // ++accumulations, Renderer.hpp:74
 	uint32_t rng = hash_2d(acc, (tile * kTileSize + ID) * (fp.max_bounces * 2u + 1u));
 	const float s0 = rand_unit_float(rng);
@@ -650,18 +694,18 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // INTERSECTION — Traverse, BVH.hpp:309-360
 // ------------------------------------------------------------------------------------------------
 // Drain one ray queue with the persistent-wave loop (dispatch on the staged-BVH variant).
-template <bool ANYHIT, bool COUNT, class LoadRay, class StoreResult>
+template <int MODE, bool COUNT, class LoadRay, class StoreResult>
 MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
-                         LoadRay load_ray, StoreResult store_result) {
+                         LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f }) {
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
-		if (!sc.stack16) trace_persistent<ANYHIT, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);   // > 65535 records: never all in LDS
-		else if (all) trace_persistent<ANYHIT, COUNT, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 65535 records: never all in LDS
+		else if (all) trace_persistent<MODE, COUNT, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else trace_persistent<MODE, COUNT, false, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 	} else {
-		if (all) trace_persistent<ANYHIT, COUNT, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
-		else trace_persistent<ANYHIT, COUNT, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result);
+		if (all) trace_persistent<MODE, COUNT, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else trace_persistent<MODE, COUNT, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 	}
 }
 
@@ -730,8 +774,11 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 // persistent kernel halves the number of tails: a wave that runs out of closest-hit rays moves on to the shadow queue.
 // Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
 // 8 waves/SIMD (= two 16-wave workgroups per CU, the LDS plan of the binary16 layout) caps the kernel at 64 VGPRs.
-// PRIMARY = bounce 0: the rays are generated from their stream index (primary_ray), nothing is read; no shadow rays are pending.
-template <bool COUNT, bool PRIMARY>
+// PRIMARY != 0 = bounce 0: the rays are generated from their index (primary_ray), nothing is read; no shadow rays are pending.
+//   kPrimaryAll: every ray i of the batch, numbered 0 .. n_pix * batch_n - 1;  kPrimaryList: the rays whose index k_primary_hits
+//   listed in in.path (pixels without a candidate list), closest_queue = that list; results are stored under the ray's index.
+constexpr int kPrimaryNone = 0, kPrimaryAll = 1, kPrimaryList = 2;
+template <bool COUNT, int PRIMARY>
 __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FrameParams fp,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                        Queue closest_queue, uint32_t* closest_work,
@@ -739,11 +786,11 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
                                                        Queue shadow_queue, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
                                                        DevCounters* ctr) {
 	extern __shared__ float4 lds[];
-	if (PRIMARY) closest_queue.n = nullptr;                                    // identity numbering: ray i is slot i
-	const uint32_t nc = PRIMARY ? fp.n_pix * fp.batch_n : queue_total(closest_queue), ns = PRIMARY ? 0u : queue_total(shadow_queue);
+	if (PRIMARY == kPrimaryAll) closest_queue.n = nullptr;                     // identity numbering: ray i is slot i
+	const uint32_t nc = PRIMARY == kPrimaryAll ? fp.n_pix * fp.batch_n : queue_total(closest_queue), ns = PRIMARY ? 0u : queue_total(shadow_queue);
 	if (nc + ns == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		if (nc) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));
+		if (nc && PRIMARY != kPrimaryList) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));     // (k_primary_hits has counted the whole batch)
 		if (ns) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(ns));
 	}
 	uint32_t c_nodes = 0, c_spheres = 0, s_nodes = 0, s_spheres = 0, c_term = 0;
@@ -752,23 +799,23 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 		const TraceLds tl = stage_bvh(sc, lds);
 		{
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-				if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
+				if (PRIMARY) { uint32_t path; primary_ray(fp, PRIMARY == kPrimaryList ? in.path[i] : i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
 				else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
 				tf = MIRT_FLT_MAX;                                                 // hit reset, Renderer.hpp:150-158
 			};
-			auto store_result = [&](uint32_t i, const Trav& t, bool) { tfar_out[i] = t.tfar; prim_out[i] = t.prim; };
-			trace_queue<false, COUNT>(sc, tl, closest_queue, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
+			auto store_result = [&](uint32_t i, const Trav& t, bool) { const uint32_t o = PRIMARY == kPrimaryList ? in.path[i] : i; tfar_out[o] = t.tfar; prim_out[o] = t.prim; };
+			trace_queue<kClosest, COUNT>(sc, tl, closest_queue, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
 		if (!PRIMARY) {
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
 				shadow_origin(sh, sink, i, px, py, pz); dx = sh.dx[i]; dy = sh.dy[i]; dz = sh.dz[i]; tf = sh.tfar[i];
 			};
 			auto store_result = [&](uint32_t i, const Trav&, bool occluded) { shadow_finish(sh, sink, i, occluded, c_term); };
-			trace_queue<true, COUNT>(sc, tl, shadow_queue, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
+			trace_queue<kAnyHit, COUNT>(sc, tl, shadow_queue, ns, shadow_work, fat_shadow, s_nodes, s_spheres, load_ray, store_result);
 		}
 	} else {
 		// brute force over all prims (the reference as shipped); also the no-spheres case
-		const QueueView qc = PRIMARY ? queue_identity(nc) : queue_view(closest_queue);
+		const QueueView qc = PRIMARY == kPrimaryAll ? queue_identity(nc) : queue_view(closest_queue);      // (kPrimaryList is never launched without a tree)
 		const QueueView qs = PRIMARY ? queue_identity(0u) : queue_view(shadow_queue);
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < nc; base += gridDim.x * kTraceBlock) {
 			const bool active = base + threadIdx.x < nc;
@@ -801,7 +848,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 // Fat rays (see trav_begin): one workgroup per ray runs the reference's brute-force loops over ALL prims —
 // intersect_prims (BVH.hpp:236-288; closest = lexicographic minimum of (dist, prim index), i.e. the ascending strict-'<' scan)
 // for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
-template <bool COUNT, bool PRIMARY>
+template <bool COUNT, int PRIMARY>
 __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
                                                     ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr) {
 	__shared__ float s_t[16];
@@ -809,7 +856,7 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp,
 	const uint32_t nc = min(*fat_closest.count, fat_closest.capacity), ns = min(*fat_shadow.count, fat_shadow.capacity);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
 	for (uint32_t k = blockIdx.x; k < nc; k += gridDim.x) {
-		const uint32_t i = fat_closest.rays[k];
+		const uint32_t i = PRIMARY == kPrimaryList ? in.path[fat_closest.rays[k]] : fat_closest.rays[k];
 		float px, py, pz, dx, dy, dz;
 		if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
 		else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
@@ -849,6 +896,76 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp,
 			if (COUNT) atomicAdd(&ctr->shadow_spheres, static_cast<unsigned long long>(sc.n_spheres));
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// PRIMARY RAYS THROUGH PER-PIXEL CANDIDATE LISTS (see kCollect above)
+// ------------------------------------------------------------------------------------------------
+// One cone per local pixel: axis = Camera::generate_ray (Camera.hpp:80-88) through the pixel centre, half-angle rho (host:
+// 0.7072 / |projection.z| + margins — the jitter moves a sample by at most half a pixel per axis in the image plane, whose
+// points are at least |z| from the eye).  Same persistent-wave traversal as k_trace; the result is the pixel's candidate list.
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, FrameParams fp, uint32_t* __restrict__ cand, float rho, uint32_t* work, FatList unused, DevCounters* ctr) {
+	extern __shared__ float4 lds[];
+	const uint32_t n = fp.n_pix;
+	if (n == 0 || static_cast<uint64_t>(blockIdx.x) * 64u >= n) return;
+	const TraceLds tl = stage_bvh(sc, lds);
+	uint32_t c_nodes = 0, c_spheres = 0;
+	auto load_ray = [&](uint32_t pix, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
+		uint32_t tile; int32_t x, y;
+		pixel_xy(fp, pix, tile, x, y);
+		const f3 d = camera_ray_dir(fp.cam, x, y, 0.5f, 0.5f);
+		px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; dx = d.x; dy = d.y; dz = d.z; tf = MIRT_FLT_MAX;
+	};
+	auto store_result = [&](uint32_t pix, const Trav& t, bool) {
+		cand[static_cast<size_t>(pix) * kCandStride] = static_cast<uint32_t>(t.prim) > kCandMax ? kCandOverflow : static_cast<uint32_t>(t.prim);
+	};
+	trace_queue<kCollect, COUNT>(sc, tl, Queue{ nullptr, 0u }, n, work, unused, c_nodes, c_spheres, load_ray, store_result, Collect{ cand, rho });
+	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
+}
+// Traverse (BVH.hpp:309-360) for the primary rays of a batch, given the lists: each ray is intersected with its pixel's candidates
+// by the reference's own arithmetic (sphere_closest_tie: the (dist, prim index) minimum does not depend on the order of the list);
+// rays of pixels without a list are compacted into `fallback` (their indices in fallback_idx) for k_trace<kPrimaryList>.
+template <bool COUNT>
+__global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint4* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
+                                                              uint32_t* __restrict__ fallback_idx, Queue fallback, DevCounters* ctr) {
+	__shared__ uint32_t append_scratch[72];
+	const uint32_t total = fp.n_pix * fp.batch_n;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&ctr->rays, static_cast<unsigned long long>(total));
+	uint32_t parity = 0, c_spheres = 0;
+	for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock, parity ^= 1u) {
+		const uint32_t i = base + threadIdx.x;
+		bool fall_back = false;
+		if (i < total) {
+			uint32_t path; float dx, dy, dz;
+			primary_ray(fp, i, path, dx, dy, dz);
+			const uint32_t pix = path & 0xffffffu;
+			const uint4* rec = cand + static_cast<size_t>(pix) * (kCandStride / 4u);
+			const uint4 r0 = rec[0];
+			const uint32_t cnt = r0.x;
+			if (cnt == kCandOverflow) fall_back = true;
+			else {
+				uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
+				if (cnt > 3u) r1 = rec[1];                                         // most lists hold one to three spheres: the rest of the record is rarely needed
+				if (cnt > 7u) { r2 = rec[2]; r3 = rec[3]; }
+				const uint32_t ids[kCandMax] = { r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
+				float tfar = MIRT_FLT_MAX; int32_t prim = -1;                      // hit reset, Renderer.hpp:150-158
+#pragma unroll
+				for (uint32_t k = 0; k < kCandMax; k++) {
+					if ((k == 3u || k == 7u) && __ballot(k < cnt) == 0ull) break;   // wave-uniform early exit
+					if (k < cnt) {
+						sphere_closest_tie(sc.spheres[ids[k]], static_cast<int32_t>(ids[k]), fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2], dx, dy, dz, tfar, prim);
+						if (COUNT) c_spheres++;
+					}
+				}
+				tfar_out[i] = tfar; prim_out[i] = prim;
+			}
+		}
+		uint32_t slot, unused_slot;
+		block_append2(fall_back, false, fallback, fallback, (base / kShadeBlock) % kSegs, append_scratch, parity, slot, unused_slot);
+		if (fall_back) fallback_idx[slot] = i;
+	}
+	if (COUNT) wave_sum(c_spheres, &ctr->spheres);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ struct PipeSlot {
 	DeviceBuffer counts;             // ray queues (kSegs counters each): stream[nb+1] | shadow[nb] | one always-empty queue; then work_next[nb] | work_next_shadow[nb] | fat counts[2 nb]
 	DeviceBuffer contrib;            // this batch's adds, same layout as the accumulator
 	DeviceBuffer fat;                // fat-ray index lists: [closest kFatCapacity][shadow kFatCapacity]
+	DeviceBuffer cand;               // per local pixel: candidate spheres of its bundle of camera rays (k_primary_cand), kCandStride words
 	hipEvent_t batch_done = nullptr; // recorded on `stream` after the batch's last kernel
 	hipEvent_t merged = nullptr;     // recorded on the main stream after the batch was merged (slot reusable)
 	bool in_use = false;
@@ -77,7 +78,7 @@ struct mirt_ctx {
 	hipStream_t stream = nullptr;
 	std::string error;
 
-	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, 0, { 0, 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
+	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, 0, 0, { 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t first_tile = 0, n_tiles = 0;
 	uint32_t run_tiles = 0, stride_tiles = 0;   // interleaved tile rows (mirt_set_tile_rows); stride 0 = one contiguous range
@@ -229,7 +230,7 @@ int ensure_streams(mirt_ctx* c) {
 	HIP_TRY(c, sync_all(c));
 	while (c->slots.size() > want) {
 		PipeSlot& sl = c->slots.back();
-		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release();
+		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release(); sl.cand.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -259,6 +260,7 @@ int ensure_streams(mirt_ctx* c) {
 		}
 		HIP_TRY(c, sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)));
 		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
+		HIP_TRY(c, sl.cand.ensure(static_cast<size_t>(n_pix) * kCandStride * sizeof(uint32_t)));
 		if (contrib) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
 		char* p = sl.arena.as<char>();
 		auto take = [&]() { void* r = p; p += plane_bytes; return r; };
@@ -324,6 +326,8 @@ struct Bracket {
 	}
 };
 
+float bundle_half_angle(const mirt_ctx* c) { return (0.7072f / std::fabs(c->camera.z)) * 1.01f + 1e-4f; }
+
 FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n) {
 	FrameParams fp{};
 	fp.cam = c->camera;
@@ -373,6 +377,13 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	uint32_t* work_next_shadow = work_next + nb;
 	uint32_t* fat_n_closest = work_next_shadow + nb;    // per-launch fat-ray counts (closest-hit list, shadow list)
 	uint32_t* fat_n_shadow = fat_n_closest + nb;
+	uint32_t* misc = fat_n_shadow + nb;                 // [0] work counter of k_primary_cand, [1] an unused fat-ray count
+	// Camera rays of a batch go through per-pixel candidate lists when a pixel is sampled often enough to pay for its cone traversal
+	// (policy.trace_primary_rays = 1 switches that off: every primary ray then walks the tree; results are identical either way).
+	const bool bundle = c->policy.use_bvh && c->scene.n_recs != 0 && !c->policy.trace_primary_rays && batch_n >= 3 && c->camera.z != 0.0f;
+	// half-angle of a pixel's bundle: half a pixel diagonal (0.7072) at distance >= |z|; + 1e-4: a sample's own cone half-width (1.38e-3 ..
+	// 1.47e-3, from |D|^2 - 1 of its normalised direction) may exceed the axis ray's by 8.5e-5
+	const float rho = bundle ? bundle_half_angle(c) : 0.0f;
 	DevCounters* ctr = c->counters.as<DevCounters>();
 	float* accum = contrib ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
@@ -406,8 +417,18 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		    // the few rays too "fat" for the tree: brute force, one workgroup each
 		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
 		  };
-		  if (bounce == 0) { if (count) launch_trace(k_trace<true, true>, k_trace_fat<true, true>); else launch_trace(k_trace<false, true>, k_trace_fat<false, true>); }
-		  else             { if (count) launch_trace(k_trace<true, false>, k_trace_fat<true, false>); else launch_trace(k_trace<false, false>, k_trace_fat<false, false>); } }
+		  if (bounce == 0 && bundle) {
+		    // camera rays through per-pixel candidate lists (kernels.hpp kCollect): one cone traversal per pixel, then exact sphere tests
+		    // per sample; rays of pixels without a list come back in stream_queue(0) / in.path and are traced like any other ray
+		    const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
+		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
+		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
+		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    if (count) launch_trace((k_trace<true, kPrimaryList>), (k_trace_fat<true, kPrimaryList>)); else launch_trace((k_trace<false, kPrimaryList>), (k_trace_fat<false, kPrimaryList>));
+		  }
+		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
+		  else                  { if (count) launch_trace((k_trace<true, kPrimaryNone>), (k_trace_fat<true, kPrimaryNone>)); else launch_trace((k_trace<false, kPrimaryNone>), (k_trace_fat<false, kPrimaryNone>)); } }
 		{ Bracket t(c, MIRT_K_SHADE, st);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr); }
@@ -493,7 +514,7 @@ int mirt_destroy(mirt_ctx* c) {
 	(void)sync_all(c);
 	harvest(c);
 	for (PipeSlot& sl : c->slots) {
-		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release();
+		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release(); sl.cand.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -629,10 +650,11 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
 	{
 		const int lds_max = static_cast<int>(kLdsPerCu);
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-		HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+		const void* dyn_lds_kernels[] = { reinterpret_cast<const void*>(&k_trace<true, kPrimaryNone>), reinterpret_cast<const void*>(&k_trace<false, kPrimaryNone>),
+		                                  reinterpret_cast<const void*>(&k_trace<true, kPrimaryAll>), reinterpret_cast<const void*>(&k_trace<false, kPrimaryAll>),
+		                                  reinterpret_cast<const void*>(&k_trace<true, kPrimaryList>), reinterpret_cast<const void*>(&k_trace<false, kPrimaryList>),
+		                                  reinterpret_cast<const void*>(&k_primary_cand<true>), reinterpret_cast<const void*>(&k_primary_cand<false>) };
+		for (const void* k : dyn_lds_kernels) HIP_TRY(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
 	}
 	for (int k = 0; k < 3; k++) s.ambient[k] = ambient_color[k];
 	s.hdri_w = static_cast<int32_t>(hdri_w); s.hdri_h = static_cast<int32_t>(hdri_h);
@@ -891,9 +913,9 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	uint32_t* misc = cn + 2 * kQueueWords;
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
-	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
+	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
 	                   Queue{ cn, 0u }, misc, ShadowBuf{}, ShadowSink{}, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
@@ -926,9 +948,9 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
 	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
-	hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
+	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
 	                   Queue{ cn, 0u }, misc, sh, sink, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, false>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
@@ -951,6 +973,31 @@ int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) 
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(out, dout.ptr, n * n_out[fn] * 4, hipMemcpyDeviceToHost);
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_math: %s", hipGetErrorString(e));
+	return MIRT_OK;
+}
+
+int mirt_debug_primary_lists(mirt_ctx* c, uint32_t hist[10]) {
+	int r = check_ready(c); if (r) return r;
+	if (!hist) return fail(c, MIRT_ERR_ARG, "hist is NULL");
+	if (!c->policy.use_bvh || c->scene.n_recs == 0) return fail(c, MIRT_ERR_STATE, "needs policy.use_bvh and a tree");
+	{ const int fr = flush_deferred(c); if (fr) return fr; }
+	HIP_TRY(c, hipSetDevice(c->device));
+	if ((r = ensure_streams(c))) return r;
+	HIP_TRY(c, sync_all(c));
+	PipeSlot& sl = c->slots[0];
+	const FrameParams fp = frame_params(c, 0, 1);
+	SceneDev sc = c->scene; sc.use_bvh = 1; sc.chunk_max = c->tune_chunk;
+	uint32_t* misc = sl.counts.as<uint32_t>();
+	HIP_TRY(c, hipMemsetAsync(misc, 0, 64, c->stream));
+	const float rho = bundle_half_angle(c);
+	const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
+	hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, c->counters.as<DevCounters>());
+	HIP_TRY(c, hipGetLastError());
+	std::vector<uint32_t> host(static_cast<size_t>(fp.n_pix) * kCandStride);
+	HIP_TRY(c, hipMemcpyAsync(host.data(), sl.cand.ptr, host.size() * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (int k = 0; k < 10; k++) hist[k] = 0;
+	for (size_t p = 0; p < fp.n_pix; p++) { const uint32_t n = host[p * kCandStride]; hist[n == kCandOverflow ? 9 : std::min<uint32_t>(n, 8u)]++; }     // hist[8]: 8 or more
 	return MIRT_OK;
 }
 

@@ -85,7 +85,10 @@ typedef struct mirt_policy {
 	uint32_t gpu_build;     /* 1: the GPU-internal traversal tree is built on the GPU at mirt_set_scene (Morton-order LBVH, milliseconds) instead of
 	                         * the host SAH sweep (better tree, 0.3 s per 100 k spheres): for the edit-rebuild loop (Application.cpp:508).  Results
 	                         * are identical either way; ignored with reference_tree = 1 or fewer than 2 spheres.  Read at mirt_set_scene. */
-	uint32_t _reserved[2];
+	uint32_t trace_primary_rays; /* 0 (default): within a batch, the camera rays of a pixel (up to 64 jittered samples) share ONE cone traversal that lists the
+	                         * spheres they can hit; each sample then tests only those, with the reference's arithmetic.  1: every primary ray walks the
+	                         * tree by itself (measurements; the traversal-twin counter checks).  Results are identical either way. */
+	uint32_t _reserved[1];
 } mirt_policy;
 
 typedef struct mirt_counters {
@@ -255,6 +258,9 @@ int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out
  * out[0] records, out[1] records staged in LDS, out[2] spheres staged in LDS, out[3] tree depth, out[4] 1 if the 32-B
  * binary16 records are in use, out[5] dynamic LDS bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
 int mirt_debug_info(mirt_ctx* ctx, uint32_t out[8]);
+/* Length histogram of the per-pixel candidate lists of the current scene / camera / size (policy.trace_primary_rays = 0 path):
+ * hist[n] = local pixels whose bundle of camera rays can hit n spheres (n = 0..8), hist[9] = pixels without a list (traced normally). */
+int mirt_debug_primary_lists(mirt_ctx* ctx, uint32_t hist[10]);
 /* Test knob: forbid (0) / allow (1, default) the binary16 records; takes effect at the next mirt_set_scene. */
 int mirt_debug_allow_half_boxes(mirt_ctx* ctx, int allow);
 

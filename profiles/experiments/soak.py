@@ -15,13 +15,21 @@ while time.time() < t_end:
     sc = mirt.scene.synthetic(n, ambient=float(rng.choice([0.0, 0.5])), scene_seed=int(rng.integers(1, 1 << 30)))
     if rng.random() < 0.3:                                   # squash the scene onto a plane / a line now and then
         sc.geometry["position"][1:, int(rng.integers(0, 3))] = 0.5
-    w, h = int(rng.choice([64, 96, 208, 512])), int(rng.choice([48, 64, 160, 256]))
+    if rng.random() < 0.6:                                   # a random camera: anywhere in or around the sphere field (also inside spheres), any direction, wide to narrow lens
+        L = float(2.0 * np.cbrt(n))
+        eye = rng.uniform(-1.5 * L, 1.5 * L, 3); eye[1] = rng.uniform(-0.5, 1.5 * L)
+        if rng.random() < 0.2 and n > 2:
+            eye = sc.geometry["position"][int(rng.integers(1, n))] + rng.normal(size=3) * 0.3      # next to / inside a sphere
+        d = rng.normal(size=3)
+        sc.camera = mirt.scene.Camera(eye=tuple(float(v) for v in eye), direction=tuple(float(v) for v in d / np.linalg.norm(d)),
+                                      focal_length=float(rng.choice([12.0, 24.0, 40.0, 85.0, 200.0])), exposure=1.0)
+    w, h = int(rng.choice([64, 96, 208, 512, 1024])), int(rng.choice([48, 64, 160, 256, 768]))
     mb, buckets, mis = int(rng.integers(1, 10)), int(rng.choice([1, 3, 5, 8, 16])), bool(rng.random() < 0.8)
     spp = int(rng.integers(1, 24))
     ref = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, mis=mis, use_bvh=False, streams=1, max_batch=int(rng.choice([0, 1, 5])))
     ref.Resize(w, h); ref.Accumulate(spp); want = ref.accumulator(); cw = ref.counters(); ref.close()
     kw = dict(gpu_build=bool(rng.random() < 0.5), reference_tree=bool(rng.random() < 0.2), allow_half_boxes=bool(rng.random() < 0.7),
-              streams=int(rng.choice([1, 2, 3, 5])), max_batch=int(rng.choice([0, 1, 3, 7, 32, 64])))
+              streams=int(rng.choice([0, 1, 2, 3, 5])), max_batch=int(rng.choice([0, 0, 1, 3, 7, 32, 64])), trace_primary_rays=bool(rng.random() < 0.15))
     r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, mis=mis, use_bvh=True, **kw); r.Resize(w, h)
     left = spp
     while left:                                              # split the calls randomly, mixing sync and async

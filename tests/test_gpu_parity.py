@@ -214,7 +214,7 @@ def test_accumulate_matches_golden(mirt, name, use_bvh):
 def test_accumulate_matches_live_oracle(mirt, scene_name, w, h, spp, mb):
     sc = make_scene(mirt, scene_name)
     o = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
-    r = mirt.Renderer(sc, max_bounces=mb, use_bvh=(scene_name != "S8a"), count_traffic=True); r.Resize(w, h); r.Accumulate(spp)
+    r = mirt.Renderer(sc, max_bounces=mb, use_bvh=(scene_name != "S8a"), count_traffic=True, trace_primary_rays=True); r.Resize(w, h); r.Accumulate(spp)
     assert_same(r.accumulator(), o.accumulator(), "accumulator")
     if spp % 5 == 0:
         assert r.Render(); assert_same(r.GetFrame(), o.Render(), "frame")
@@ -237,7 +237,7 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     spheres the oracle's twin visits for the same variant."""
     sc = mirt.scene.synthetic(1000, ambient=0.5)
     o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(128, 128); o.Accumulate(5)
-    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, reference_tree=reference_tree, count_traffic=True)
+    r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, reference_tree=reference_tree, count_traffic=True, trace_primary_rays=True)
     r.Resize(128, 128); r.Accumulate(5)
     info = r.debug_info()
     assert info["half_boxes"] == int(allow_half) and info["records"] == 999 and info["lds_records"] == 999 and info["lds_spheres"] == 1000
@@ -248,7 +248,7 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     assert cg["nodes"] == ct["nodes"] and cg["spheres"] == ct["spheres"]
     assert cg["shadow_nodes"] == ct["shadow_nodes"] and cg["shadow_spheres"] == ct["shadow_spheres"]
     if not reference_tree:
-        ref = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, count_traffic=True); ref.Resize(128, 128); ref.Accumulate(5)
+        ref = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, count_traffic=True, trace_primary_rays=True); ref.Resize(128, 128); ref.Accumulate(5)
         assert cg["nodes"] < 0.6 * ref.counters()["nodes"]          # the internal SAH tree roughly halves the box tests
         ref.close()
     r.close()
@@ -698,6 +698,27 @@ def test_full_size_bvh_equals_brute_force(mirt, name, spp):
     fast.close(); slow.close()
     assert_same(a, b, f"{name} full size: BVH pipeline vs brute force")
     assert np.isfinite(a).all() and (a >= 0).all()
+
+
+@pytest.mark.parametrize("scene_name,w,h,spp,mb", [("default9", 160, 96, 10, 16), ("S1000a", 256, 128, 16, 5), ("S20000", 320, 192, 8, 6), ("bvh_test", 128, 96, 10, 16), ("S1000a", 32, 16, 5, 5)])
+def test_primary_rays_through_pixel_candidate_lists(mirt, scene_name, w, h, spp, mb):
+    """The camera rays of a batch share one cone traversal per pixel that lists the spheres its jittered samples can hit
+    (kernels.hpp kCollect / k_primary_cand / k_primary_hits); pixels whose list overflows are traced normally.  Same
+    accumulators bit for bit as with every primary ray walking the tree (policy.trace_primary_rays) and as the brute-force
+    oracle, the same ray counts, and far fewer box tests.  32x16: a bundle wider than the tree can take -> every pixel falls back."""
+    sc = mirt.scene.synthetic(20000) if scene_name == "S20000" else mirt.scene.bvh_test() if scene_name == "bvh_test" else make_scene(mirt, scene_name)
+    a = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, count_traffic=True); a.Resize(w, h); a.Accumulate(spp)
+    b = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, count_traffic=True, trace_primary_rays=True); b.Resize(w, h); b.Accumulate(spp)
+    assert_same(a.accumulator(), b.accumulator(), f"{scene_name}: candidate lists vs traced primary rays")
+    ca, cb = a.counters(), b.counters()
+    for k in ("rays", "shadow_rays", "terminated", "dropped", "shadow_nodes"):
+        assert ca[k] == cb[k], k
+    if w >= 128:
+        assert ca["nodes"] < cb["nodes"]                     # the primary rays' box tests are gone (one cone per pixel instead)
+    if scene_name != "S20000":
+        o = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+        assert_same(a.accumulator(), o.accumulator(), f"{scene_name}: candidate lists vs brute-force oracle")
+    a.close(); b.close()
 
 
 def test_cfg5_policy_16_buckets_17_bounces(mirt):
