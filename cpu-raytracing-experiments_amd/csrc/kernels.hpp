@@ -929,11 +929,10 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, Fr
 template <bool COUNT>
 __global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint4* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                               uint32_t* __restrict__ fallback_idx, Queue fallback, DevCounters* ctr) {
-	__shared__ uint32_t append_scratch[72];
 	const uint32_t total = fp.n_pix * fp.batch_n;
 	if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&ctr->rays, static_cast<unsigned long long>(total));
-	uint32_t parity = 0, c_spheres = 0;
-	for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock, parity ^= 1u) {
+	uint32_t c_spheres = 0;
+	for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
 		const uint32_t i = base + threadIdx.x;
 		bool fall_back = false;
 		if (i < total) {
@@ -961,9 +960,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, Frame
 				tfar_out[i] = tfar; prim_out[i] = prim;
 			}
 		}
-		uint32_t slot, unused_slot;
-		block_append2(fall_back, false, fallback, fallback, (base / kShadeBlock) % kSegs, append_scratch, parity, slot, unused_slot);
-		if (fall_back) fallback_idx[slot] = i;
+		// rays without a list (a few per cent, clustered) are appended per WAVE, one atomic for the waves that have any: no workgroup
+		// barrier in this kernel.  All waves of a block-iteration use its segment, so the segment capacity argument of k_shade holds.
+		const unsigned long long m = __ballot(fall_back);
+		if (m != 0ull) {
+			const uint32_t seg = (base / kShadeBlock) % kSegs;
+			uint32_t first = 0;
+			if (lane_id() == 0) first = atomicAdd(fallback.n + seg * kSegPitch, static_cast<uint32_t>(__popcll(m)));
+			first = __builtin_amdgcn_readfirstlane(first);
+			if (fall_back) fallback_idx[seg * fallback.seg_cap + first + mask_rank(m)] = i;
+		}
 	}
 	if (COUNT) wave_sum(c_spheres, &ctr->spheres);
 }

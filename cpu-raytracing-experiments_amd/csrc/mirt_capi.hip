@@ -393,6 +393,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t tgrid = trace_grid(c, total);
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
 	const uint32_t tlds = trace_lds(c);
+	const uint32_t hgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 4u));   // k_primary_hits: 28 VGPRs, no LDS: four 8-wave workgroups per CU
 	// one workgroup per fat ray: a large scene (100 k spheres: ~100 us per ray) wants as many of them in flight as there are rays (a few hundred per launch)
 	const uint32_t fat_grid = sc.n_spheres > 4096 ? static_cast<uint32_t>(c->n_cu) * 2u : 64u;
 
@@ -423,8 +424,8 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		    const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
 		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
 		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
-		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
-		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
 		    if (count) launch_trace((k_trace<true, kPrimaryList>), (k_trace_fat<true, kPrimaryList>)); else launch_trace((k_trace<false, kPrimaryList>), (k_trace_fat<false, kPrimaryList>));
 		  }
 		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
