@@ -367,10 +367,10 @@ constexpr int kClosest = 0, kAnyHit = 1, kCollect = 2;
 //     distance on it from above, hence every sample's closest-hit distance: a sphere whose box starts beyond F cannot be a closest hit.
 // A pixel whose list would exceed kCandMax entries (silhouettes of many small spheres) is marked and its samples are traced normally.
 constexpr uint32_t kCandMax = 15, kCandStride = 16, kCandOverflow = 0xffffffffu;
-struct Collect { uint32_t* cand; float rho; };      // cand[pixel * kCandStride]: count, then up to kCandMax BVH-order prim indices
+struct Collect { uint32_t* cand; float rho; uint32_t n_pix; };      // cand[k * n_pix + pixel]: k = 0 the count, k = 1.. up to kCandMax BVH-order prim indices (plane-major: neighbouring pixels, neighbouring words)
 MIRT_DI void collect_leaf(bool on, float4 s, uint32_t prim, uint32_t pix, const Collect& col, Trav& t) {
 	uint32_t cnt = static_cast<uint32_t>(t.prim);
-	if (on & (cnt < kCandMax)) col.cand[static_cast<size_t>(pix) * kCandStride + 1u + cnt] = prim;
+	if (on & (cnt < kCandMax)) col.cand[static_cast<size_t>(1u + cnt) * col.n_pix + pix] = prim;
 	cnt += on ? 1u : 0u;
 	t.prim = static_cast<int32_t>(cnt);
 	// full cover -> every sample hits this sphere no later than F
@@ -389,7 +389,7 @@ MIRT_DI void collect_leaf(bool on, float4 s, uint32_t prim, uint32_t pix, const 
 }
 template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
 MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres,
-                       uint32_t pix = 0, const Collect col = Collect{ nullptr, 0.0f }) {
+                       uint32_t pix = 0, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
 	constexpr bool ANYHIT = MODE == kAnyHit;
 	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
 	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
@@ -546,7 +546,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n,
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
 template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
-                              LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f }) {
+                              LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
 	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n, sc.chunk_max), true };
 	Trav t;
 	TravSpill spill;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams fp, StreamBuf out
 // Drain one ray queue with the persistent-wave loop (dispatch on the staged-BVH variant).
 template <int MODE, bool COUNT, class LoadRay, class StoreResult>
 MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
-                         LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f }) {
+                         LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
@@ -918,16 +918,16 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, Fr
 		px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; dx = d.x; dy = d.y; dz = d.z; tf = MIRT_FLT_MAX;
 	};
 	auto store_result = [&](uint32_t pix, const Trav& t, bool) {
-		cand[static_cast<size_t>(pix) * kCandStride] = static_cast<uint32_t>(t.prim) > kCandMax ? kCandOverflow : static_cast<uint32_t>(t.prim);
+		cand[pix] = static_cast<uint32_t>(t.prim) > kCandMax ? kCandOverflow : static_cast<uint32_t>(t.prim);
 	};
-	trace_queue<kCollect, COUNT>(sc, tl, Queue{ nullptr, 0u }, n, work, unused, c_nodes, c_spheres, load_ray, store_result, Collect{ cand, rho });
+	trace_queue<kCollect, COUNT>(sc, tl, Queue{ nullptr, 0u }, n, work, unused, c_nodes, c_spheres, load_ray, store_result, Collect{ cand, rho, n });
 	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
 }
 // Traverse (BVH.hpp:309-360) for the primary rays of a batch, given the lists: each ray is intersected with its pixel's candidates
 // by the reference's own arithmetic (sphere_closest_tie: the (dist, prim index) minimum does not depend on the order of the list);
 // rays of pixels without a list are compacted into `fallback` (their indices in fallback_idx) for k_trace<kPrimaryList>.
 template <bool COUNT>
-__global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint4* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
+__global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint32_t* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
                                                               uint32_t* __restrict__ fallback_idx, Queue fallback, DevCounters* ctr) {
 	const uint32_t total = fp.n_pix * fp.batch_n;
 	if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&ctr->rays, static_cast<unsigned long long>(total));
@@ -939,21 +939,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, Frame
 			uint32_t path; float dx, dy, dz;
 			primary_ray(fp, i, path, dx, dy, dz);
 			const uint32_t pix = path & 0xffffffu;
-			const uint4* rec = cand + static_cast<size_t>(pix) * (kCandStride / 4u);
-			const uint4 r0 = rec[0];
-			const uint32_t cnt = r0.x;
+			const uint32_t cnt = cand[pix];
 			if (cnt == kCandOverflow) fall_back = true;
 			else {
-				uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1;
-				if (cnt > 3u) r1 = rec[1];                                         // most lists hold one to three spheres: the rest of the record is rarely needed
-				if (cnt > 7u) { r2 = rec[2]; r3 = rec[3]; }
-				const uint32_t ids[kCandMax] = { r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w };
 				float tfar = MIRT_FLT_MAX; int32_t prim = -1;                      // hit reset, Renderer.hpp:150-158
-#pragma unroll
 				for (uint32_t k = 0; k < kCandMax; k++) {
-					if ((k == 3u || k == 7u) && __ballot(k < cnt) == 0ull) break;   // wave-uniform early exit
+					if (__ballot(k < cnt) == 0ull) break;                          // wave-uniform exit: most lists hold one to three spheres
 					if (k < cnt) {
-						sphere_closest_tie(sc.spheres[ids[k]], static_cast<int32_t>(ids[k]), fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2], dx, dy, dz, tfar, prim);
+						const uint32_t id = cand[static_cast<size_t>(k + 1u) * fp.n_pix + pix];
+						sphere_closest_tie(sc.spheres[id], static_cast<int32_t>(id), fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2], dx, dy, dz, tfar, prim);
 						if (COUNT) c_spheres++;
 					}
 				}

@@ -380,7 +380,10 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	uint32_t* misc = fat_n_shadow + nb;                 // [0] work counter of k_primary_cand, [1] an unused fat-ray count
 	// Camera rays of a batch go through per-pixel candidate lists when a pixel is sampled often enough to pay for its cone traversal
 	// (policy.trace_primary_rays = 1 switches that off: every primary ray then walks the tree; results are identical either way).
-	const bool bundle = c->policy.use_bvh && c->scene.n_recs != 0 && !c->policy.trace_primary_rays && batch_n >= 3 && c->camera.z != 0.0f;
+	// (The half-angle bound assumes view.orient rotates: a non-unit quaternion, which the reference's View never holds (Camera.hpp:48-50),
+	// would shear the image plane — such a camera gets no lists.)
+	const float qn = c->camera.orient[0] * c->camera.orient[0] + c->camera.orient[1] * c->camera.orient[1] + c->camera.orient[2] * c->camera.orient[2] + c->camera.orient[3] * c->camera.orient[3];
+	const bool bundle = c->policy.use_bvh && c->scene.n_recs != 0 && !c->policy.trace_primary_rays && batch_n >= 3 && c->camera.z != 0.0f && std::fabs(qn - 1.0f) < 1e-4f;
 	// half-angle of a pixel's bundle: half a pixel diagonal (0.7072) at distance >= |z|; + 1e-4: a sample's own cone half-width (1.38e-3 ..
 	// 1.47e-3, from |D|^2 - 1 of its normalised direction) may exceed the axis ray's by 8.5e-5
 	const float rho = bundle ? bundle_half_angle(c) : 0.0f;
@@ -424,8 +427,8 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		    const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
 		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
 		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
-		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
-		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint4>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
 		    if (count) launch_trace((k_trace<true, kPrimaryList>), (k_trace_fat<true, kPrimaryList>)); else launch_trace((k_trace<false, kPrimaryList>), (k_trace_fat<false, kPrimaryList>));
 		  }
 		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
@@ -994,11 +997,11 @@ int mirt_debug_primary_lists(mirt_ctx* c, uint32_t hist[10]) {
 	const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
 	hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, c->counters.as<DevCounters>());
 	HIP_TRY(c, hipGetLastError());
-	std::vector<uint32_t> host(static_cast<size_t>(fp.n_pix) * kCandStride);
+	std::vector<uint32_t> host(static_cast<size_t>(fp.n_pix));                            // plane 0 of the lists: the counts
 	HIP_TRY(c, hipMemcpyAsync(host.data(), sl.cand.ptr, host.size() * 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	for (int k = 0; k < 10; k++) hist[k] = 0;
-	for (size_t p = 0; p < fp.n_pix; p++) { const uint32_t n = host[p * kCandStride]; hist[n == kCandOverflow ? 9 : std::min<uint32_t>(n, 8u)]++; }     // hist[8]: 8 or more
+	for (size_t p = 0; p < fp.n_pix; p++) { const uint32_t n = host[p]; hist[n == kCandOverflow ? 9 : std::min<uint32_t>(n, 8u)]++; }     // hist[8]: 8 or more
 	return MIRT_OK;
 }
 
