@@ -12,6 +12,9 @@
 //                     reference's add order
 //   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into the next stream and
 //                     NEE candidates into the shadow stream (wave64 ballot + mbcnt prefix sums, one atomic per workgroup)
+//   k_primary_cand /  bounce 0 only (RAY GENERATION + the first Traverse, Renderer.hpp:113-127,165): the camera rays have no stream — a
+//   k_primary_hits    ray is a function of its index — and the up to 64 jittered samples of a pixel share ONE cone traversal that lists
+//                     the spheres they can hit; each sample then tests only its pixel's list (kCollect below)
 //
 // Per-path results do not depend on stream slot or scheduling: every random draw is re-derived from
 // (accumulations, seed[pixel], bounce) (Renderer.hpp:107,117,255,362), which is what lets the
