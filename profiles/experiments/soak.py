@@ -23,6 +23,11 @@ while time.time() < t_end:
         d = rng.normal(size=3)
         sc.camera = mirt.scene.Camera(eye=tuple(float(v) for v in eye), direction=tuple(float(v) for v in d / np.linalg.norm(d)),
                                       focal_length=float(rng.choice([12.0, 24.0, 40.0, 85.0, 200.0])), exposure=1.0)
+    if rng.random() < 0.35:                                  # the same scene at another scale / far from the origin: f32 error margins of the cone and cover tests
+        k = float(rng.choice([0.01, 0.1, 8.0, 50.0])); off = (rng.normal(size=3) * float(rng.choice([0.0, 100.0, 3000.0]))).astype(np.float32)
+        sc.geometry["position"] = (sc.geometry["position"] * np.float32(k) + off).astype(np.float32)
+        sc.geometry["radius_sq"] = (sc.geometry["radius_sq"] * np.float32(k * k)).astype(np.float32)
+        sc.camera.pos = (sc.camera.pos * np.float32(k) + off).astype(np.float32)
     w, h = int(rng.choice([64, 96, 208, 512, 1024])), int(rng.choice([48, 64, 160, 256, 768]))
     mb, buckets, mis = int(rng.integers(1, 10)), int(rng.choice([1, 3, 5, 8, 16])), bool(rng.random() < 0.8)
     spp = int(rng.integers(1, 24))
