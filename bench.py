@@ -287,6 +287,22 @@ def main():
             assert tuple(full.shape) == (tiles, cfg["buckets"], 3, 256)
         del full
 
+    # ---- the same steps with every camera ray walking the tree by itself (policy.trace_primary_rays = 1), for comparison: by default the
+    #      jittered samples of a pixel share one cone traversal per batch (kernels.hpp, k_primary_cand); results are bit-identical ----
+    value_walk = None
+    if not args.no_counts and world == 1:
+        r.set_policy(trace_primary_rays=1)
+        r.ResetAccumulator()
+        for _ in range(W):
+            r.Accumulate(spp)
+        sync_all()
+        c0 = r.counters()["rays"]; t1 = time.perf_counter()
+        for _ in range(max(1, min(args.aux_steps, K))):
+            r.AccumulateAsync(spp)
+        sync_all()
+        value_walk = (r.counters()["rays"] - c0) / (time.perf_counter() - t1) / 1e6
+        r.set_policy(trace_primary_rays=0)
+
     # ---- roofline passes (rank 0's share of the image): the first `aux` steps after the warmup again, (a) with ONE batch in
     #      flight and HIP events around every launch, so a launch's duration is the kernel's own; (b) with the kernels counting
     #      the boxes and spheres they test ----
@@ -393,7 +409,10 @@ def main():
                                     f"(primary+{cfg['max_bounces'] - 1} bounces), {cfg['buckets']} buckets, {spp} accumulations/step; fixed image, tile rows split over the GPUs"),
                        "image": f"{width}x{height}", "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
                        "parallelism": f"tile rows interleaved over {world} GPUs, one RCCL gather" if world > 1 else "single GPU", "batches_in_flight": n_streams,
-                       "accumulations_per_batch": min(batch, spp)},
+                       "accumulations_per_batch": min(batch, spp),
+                       "primary_rays": "the jittered camera rays of a pixel share one cone traversal per batch that lists the spheres they can hit; every ray is then "
+                                       "intersected with its pixel's list by the reference's arithmetic (policy.trace_primary_rays = 0, bit-identical results)"},
+            "value_with_every_primary_ray_walking_the_tree": value_walk,
             "rays_per_step": rays_total / K,
             "shadow_rays_per_step": (counts["shadow_rays"] / aux) if counts else None,
             "kernel_ms_per_step": ({k: v["ms"] / aux for k, v in ktimes.items() if v["launches"]} if ktimes else None),
