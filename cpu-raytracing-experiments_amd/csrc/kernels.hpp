@@ -403,7 +403,10 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	uint32_t c0, c1;
 	if (HALF) {
 		v4f q0, q1;                           // 32-B record: 12 binary16 planes + 2 child references
-		if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
+		// Only the top of a large tree is staged.  The choice is made per WAVE: a step whose lanes are all in the staged block reads LDS,
+		// any other step reads every lane's record from memory (the top records are the hottest lines of L1 / L2) — one path per step
+		// instead of two exec-masked halves.
+		if (ALL_LDS || __ballot(cur >= sc.lds_recs) == 0ull) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
 		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 2ull * cur; q0 = r[0]; q1 = r[1]; }
 		const uint32_t w0 = __float_as_uint(q0.x), w1 = __float_as_uint(q0.y), w2 = __float_as_uint(q0.z), w3 = __float_as_uint(q0.w);
 		const uint32_t w4 = __float_as_uint(q1.x), w5 = __float_as_uint(q1.y);
@@ -413,7 +416,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		c0 = __float_as_uint(q1.z); c1 = __float_as_uint(q1.w);
 	} else {
 		v4f q0, q1, q2, q3;
-		if (ALL_LDS || cur < sc.lds_recs) {     // staged records are stored plane-major (q0[], q1[], q2[], q3[]): 16-B stride between lanes' addresses
+		if (ALL_LDS || __ballot(cur >= sc.lds_recs) == 0ull) {     // staged records are stored plane-major (q0[], q1[], q2[], q3[]): 16-B stride between lanes' addresses
 			const lds_v4f* r = lds.recs + cur; const uint32_t ns = sc.lds_recs;
 			q0 = r[0]; q1 = r[ns]; q2 = r[2u * ns]; q3 = r[3u * ns];
 		}
@@ -459,7 +462,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 			float4 s = s_pre;
 			const bool fetch = on & (!ALL_LDS || pass == 1 || l0 != cand);   // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
 			if (fetch) {                                                     // divergent on purpose: the load lands in s for these lanes only (a select would cost 4 + 4 moves)
-				if (ALL_LDS || first < sc.lds_spheres) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];
+				if (ALL_LDS) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];     // spheres are staged all (ALL_LDS) or none
 			}
 			if (COUNT) n_spheres += on ? 1u : 0u;
 			if (MODE == kAnyHit) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
