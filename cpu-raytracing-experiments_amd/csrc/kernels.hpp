@@ -51,7 +51,8 @@ struct SceneDev {
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
 	uint32_t chunk_max;         // rays per reservation from a launch's work counter, upper limit (pick_chunk)
-	uint32_t stack16;           // 1: record indices fit 16 bits and the LDS stack holds u16 entries (binary16 records, <= 65535 of them)
+	uint32_t leaf_batch;        // lanes of a wave that must stand at a leaf before it runs a leaf pass (trace_persistent)
+	uint32_t stack16;           // 1: record and prim indices fit 15 bits and the LDS stack holds u16 entries (binary16 records, <= 32768 records and spheres)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
 	float hdri_fw, hdri_fh;
@@ -390,13 +391,35 @@ MIRT_DI void collect_leaf(bool on, float4 s, uint32_t prim, uint32_t pix, const 
 	const float F = ((b + col.rho * len) - __builtin_sqrtf(__builtin_fmaxf(slack, 0.0f))) * 1.001f + 1e-4f;
 	t.tfar = (cover & (F < t.tfar)) ? F : t.tfar;
 }
-template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
-MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_nodes, uint32_t& n_spheres,
-                       uint32_t pix = 0, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
-	constexpr bool ANYHIT = MODE == kAnyHit;
-	// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth
-	// are consecutive, conflict-free); deeper entries (rare) use the scratch array.
+// Per-lane stack: the first kLdsStack entries live in LDS, entry-major ([entry][thread]: a wave's accesses to one depth are
+// consecutive, conflict-free); deeper entries (rare) use the scratch array.  An entry is a child reference: a record index, or
+// kLeafBit | prim.  ST16 packs it into 16 bits (index < 2^15, the leaf flag moved to bit 15; read back sign-extended).
+typedef __attribute__((address_space(3))) int16_t lds_i16;
+template <bool HALF, bool ST16>
+MIRT_DI void stack_put(const TraceLds lds, TravSpill& spill, uint32_t sp, uint32_t ref) {
+	constexpr uint32_t lds_entries = (HALF && !ST16) ? kLdsStackWide : kLdsStack;
 	constexpr uint32_t lstride = kTraceBlock;     // every trace launch uses kTraceBlock threads (a runtime blockDim.x costs a quarter-rate v_mul_lo_u32 per push and per pop)
+	if (sp < lds_entries) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(ref | (ref >> 16)); else lds.stack[sp * lstride + threadIdx.x] = ref; }
+	else if (sp < kStack) spill.e[sp - lds_entries] = ref;       // depth < kStack is validated on the host
+}
+template <bool HALF, bool ST16>
+MIRT_DI uint32_t stack_get(const TraceLds lds, const TravSpill& spill, uint32_t sp) {
+	constexpr uint32_t lds_entries = (HALF && !ST16) ? kLdsStackWide : kLdsStack;
+	constexpr uint32_t lstride = kTraceBlock;
+	if (sp < lds_entries) {
+		if (ST16) return static_cast<uint32_t>(static_cast<int32_t>(((lds_i16*)lds.stack)[sp * lstride + threadIdx.x])) & 0x80007fffu;
+		return lds.stack[sp * lstride + threadIdx.x];
+	}
+	return spill.e[sp - lds_entries];
+}
+// A ray's traversal is a depth-first walk in which LEAVES ARE STACK ITEMS like inner nodes: t.cur is either a record (node_step:
+// slab-test both children against the current tfar, enter the nearer hit child — leaf or not —, push the other, or pop) or a leaf
+// (leaf_step: intersect its sphere, then pop).  The two kinds of step are separate so that a wave can run them as separate,
+// DENSE passes (trace_persistent): with the sphere test inlined in the node step, as it was, ~58 % of the loop's VALU
+// instructions were sphere tests executed for the whole wave on behalf of the ~13 % of lanes that had a hit leaf in that step.
+// Both return true when this ray is finished (stack empty, or ANYHIT occluder found -> occluded = true, or a full kCollect list).
+template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
+MIRT_DI bool node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, uint32_t& n_nodes) {
 	const uint32_t cur = t.cur;
 	// child boxes: (lo, hi) per axis for child 0 (a) and child 1 (b)
 	float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
@@ -427,74 +450,45 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
 	}
 	if (COUNT) n_nodes += 2;
-	// The sphere of the first leaf child is requested BEFORE the slab tests (its index comes with the record), so the second
-	// LDS round trip of the step overlaps the ~40 VALU instructions of the two box tests instead of following them.
-	const bool leaf_a = static_cast<int32_t>(c0) < 0, leaf_b = static_cast<int32_t>(c1) < 0;      // kLeafBit is the sign bit
-	const uint32_t cand = leaf_a ? c0 : c1;
-	// (Only when the spheres are staged in LDS: from L2 the speculative packets of leaves whose box is then missed cost more
-	// than the overlap gains.)
-	const bool any_leaf = __ballot(leaf_a | leaf_b) != 0ull;
-	float4 s_pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	if (ALL_LDS && any_leaf) {
-		const uint32_t idx = (leaf_a | leaf_b) ? (cand & ~kLeafBit) : 0u;     // lanes without a leaf child read sphere 0 (always valid: a leaf exists)
-		if (ALL_LDS || idx < sc.lds_spheres) s_pre = to_float4(lds.spheres[idx]); else s_pre = sc.spheres[idx];
-	}
 	const RaySlab& rs = t.rs;
 	float ta, tb;
-	bool ha = slab_hit(rs, __builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
-	                   __builtin_fmaf(ay0, rs.iay, rs.nay), __builtin_fmaf(ay1, rs.iby, rs.nby),
-	                   __builtin_fmaf(az0, rs.iaz, rs.naz), __builtin_fmaf(az1, rs.ibz, rs.nbz), t.tfar, ta);
-	bool hb = slab_hit(rs, __builtin_fmaf(bx0, rs.iax, rs.nax), __builtin_fmaf(bx1, rs.ibx, rs.nbx),
-	                   __builtin_fmaf(by0, rs.iay, rs.nay), __builtin_fmaf(by1, rs.iby, rs.nby),
-	                   __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
-
-	// ---- hit leaf children are intersected at once, child 0 before child 1 (same per-ray order as the oracle's twin) ----
-	const bool la = ha & leaf_a, lb = hb & leaf_b;
-	if (any_leaf && __ballot(la | lb) != 0ull) {                  // wave-uniform guard: scalar branch, no exec-mask bookkeeping
-		// first queued leaf of this lane = child 0 if it is a hit leaf, else child 1; a second one only when both are
-		uint32_t l0 = la ? c0 : c1;
-		bool on = la | lb;
-		bool second = la & lb;
-		for (int pass = 0; pass < 2; pass++) {
-			if (pass == 1 && __ballot(second) == 0ull) break;
-			if (pass == 1) { l0 = c1; on = second; }
-			const uint32_t first = l0 & ~kLeafBit;
-			float4 s = s_pre;
-			const bool fetch = on & (!ALL_LDS || pass == 1 || l0 != cand);   // not the prefetched one: child 1 when child 0 is a leaf that was missed, or the second leaf
-			if (fetch) {                                                     // divergent on purpose: the load lands in s for these lanes only (a select would cost 4 + 4 moves)
-				if (ALL_LDS) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];     // spheres are staged all (ALL_LDS) or none
-			}
-			if (COUNT) n_spheres += on ? 1u : 0u;
-			if (MODE == kAnyHit) occluded = occluded | (on & sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar));
-			else if (MODE == kCollect) collect_leaf(on, s, first, pix, col, t);
-			else sphere_closest_sel(on, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
-		}
-	}
-	// ---- next node: selects, plus one exec region each for the conditional stack write and read ----
-	ha = ha & !leaf_a; hb = hb & !leaf_b;
-	if (!ANYHIT) { ha = ha & (ta <= t.tfar); hb = hb & (tb <= t.tfar); }        // re-check against the shrunken tfar
+	const bool ha = slab_hit(rs, __builtin_fmaf(ax0, rs.iax, rs.nax), __builtin_fmaf(ax1, rs.ibx, rs.nbx),
+	                         __builtin_fmaf(ay0, rs.iay, rs.nay), __builtin_fmaf(ay1, rs.iby, rs.nby),
+	                         __builtin_fmaf(az0, rs.iaz, rs.naz), __builtin_fmaf(az1, rs.ibz, rs.nbz), t.tfar, ta);
+	const bool hb = slab_hit(rs, __builtin_fmaf(bx0, rs.iax, rs.nax), __builtin_fmaf(bx1, rs.ibx, rs.nbx),
+	                         __builtin_fmaf(by0, rs.iay, rs.nay), __builtin_fmaf(by1, rs.iby, rs.nby),
+	                         __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
+	// ---- next item: selects, plus one exec region each for the conditional stack write and read ----
 	const bool both = ha & hb, none = !(ha | hb);
 	const bool a_first = ta <= tb;                                            // any-hit rays too: an occluder is most likely close to the origin (the result does not depend on the order)
-	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one inner child is hit
-	const uint32_t far = a_first ? c1 : c0;                                   // inner reference = record index; depth < 64 is validated on the host
-	constexpr uint32_t lds_entries = (HALF && !ST16) ? kLdsStackWide : kLdsStack;
+	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one child is hit
+	const uint32_t far = a_first ? c1 : c0;
 	uint32_t sp = t.sp;
-	if (both) {
-		if (sp < lds_entries) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(far); else lds.stack[sp * lstride + threadIdx.x] = far; }
-		else if (sp < kStack) spill.e[sp - lds_entries] = far;
-		sp += 1u;
-	}
+	if (both) { stack_put<HALF, ST16>(lds, spill, sp, far); sp += 1u; }
 	uint32_t next = near;
 	const bool pop = none & (sp != 0u);
-	if (pop) {
-		--sp;
-		if (sp < lds_entries) next = ST16 ? static_cast<uint32_t>(((lds_u16*)lds.stack)[sp * lstride + threadIdx.x]) : lds.stack[sp * lstride + threadIdx.x];
-		else next = spill.e[sp - lds_entries];
-	}
-	const bool finished = (ANYHIT & occluded) | (none & !pop) | ((MODE == kCollect) & (static_cast<uint32_t>(t.prim) > kCandMax));   // a full list: the pixel falls back to tracing
+	if (pop) { --sp; next = stack_get<HALF, ST16>(lds, spill, sp); }
 	t.sp = sp;
 	t.cur = next;
-	return finished;
+	return none & !pop;
+}
+template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
+MIRT_DI bool leaf_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_spheres, uint32_t pix, const Collect& col) {
+	const uint32_t first = t.cur & ~kLeafBit;
+	// (Requesting the sphere when the lane ARRIVES at the leaf, into four registers kept until the pass, was measured: 22 VGPR
+	// spills and k_trace 253 -> 283 ms per cfg4 step.  The other seven waves of the SIMD cover this load.)
+	float4 s;
+	if (ALL_LDS) s = to_float4(lds.spheres[first]); else s = sc.spheres[first];     // spheres are staged all (ALL_LDS) or none
+	if (COUNT) n_spheres += 1u;
+	bool fin = false;
+	if (MODE == kAnyHit) { occluded = sphere_occludes_sel(s, t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar); fin = occluded; }
+	else if (MODE == kCollect) { collect_leaf(true, s, first, pix, col, t); fin = static_cast<uint32_t>(t.prim) > kCandMax; }   // a full list: the pixel falls back to tracing
+	else sphere_closest_sel(true, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
+	uint32_t sp = t.sp;
+	const bool pop = !fin & (sp != 0u);
+	if (pop) { --sp; t.cur = stack_get<HALF, ST16>(lds, spill, sp); }
+	t.sp = sp;
+	return !pop;
 }
 
 // ---- persistent waves with in-kernel lane refill ------------------------------------------------------------
@@ -504,6 +498,7 @@ MIRT_DI bool trav_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 // kRefillIdle lanes are idle they are given the next rays of the window — slot = wbeg + rank among idle lanes, from a
 // wave64 ballot + mbcnt prefix sum — and the wave goes back to stepping all lanes together.
 constexpr uint32_t kChunkMax = 512;    // default of SceneDev::chunk_max.  Measured (k_trace ms per step, 256 / 512 / 4096): cfg2 14.9 / 13.6 / 14.1, cfg4 - / 381.5 / 402.3 (larger chunks: uneven tails)
+constexpr uint32_t kLeafBatch = 16;    // default of SceneDev::leaf_batch.  Measured (k_trace ms per cfg4 step; 8 / 16 / 24 / 32 / 40): 252.9 / 247.7 / 253.1 / 274.2 / 314.8; before the split 284.9
 constexpr uint32_t kRefillIdle = 32;   // measured on cfg2: 8 -> 15.3 ms of trace per step, 16 -> 13.9, 24..40 -> 13.5 (a refill runs the ~200-instruction ray set-up on the whole wave)
 constexpr uint32_t kNone = 0xffffffffu;
 struct FatList { uint32_t* count; uint32_t* rays; uint32_t capacity; };
@@ -580,8 +575,19 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		if (__ballot(ri != kNone) == 0ull) { if (!work_left) break; continue; }
 		const bool can_refill = work_left;
 		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
+		// One pass per iteration, chosen for the whole wave: a LEAF pass (the lanes standing at a leaf intersect their sphere) once
+		// at least sc.leaf_batch lanes wait for one or no lane stands at a record, a NODE pass otherwise.  A waiting lane loses the
+		// node passes it sits out; the sphere test (~50 VALU instructions with its correctly rounded sqrt) runs at several times
+		// the lane density it had inside the node step.
 		for (;;) {
-			if (ri != kNone && !done) done = trav_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_nodes, c_spheres, ri, col);
+			const bool run = ri != kNone && !done;
+			const bool at_leaf = run & (static_cast<int32_t>(t.cur) < 0);            // kLeafBit is the sign bit
+			const unsigned long long leaf_m = __ballot(at_leaf), node_m = __ballot(run & !at_leaf);
+			if (node_m == 0ull || static_cast<uint32_t>(__popcll(leaf_m)) >= sc.leaf_batch) {
+				if (at_leaf) done = leaf_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_spheres, ri, col);
+			} else {
+				if (run & !at_leaf) done = node_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, c_nodes);
+			}
 			const unsigned long long running = __ballot(ri != kNone && !done);
 			if (running == 0ull) break;
 			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;

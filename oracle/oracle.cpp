@@ -837,9 +837,10 @@ static inline void sphere_closest_tie(const Sphere& s, int32_t prim_ID, float px
 	if (id < 0) return;
 	if (t < *tfar || (t == *tfar && (*primID < 0 || prim_ID < *primID))) { *tfar = t; *primID = prim_ID; }
 }
-// Same step order as traverse_bvh() in csrc/kernels.hpp: at an inner node test both child boxes against the
-// current tfar; hit leaf children are intersected at once; inner children are re-checked against the possibly
-// shrunken tfar, the nearer one is entered first and the other pushed.  (The root box itself is not tested.)
+// Same per-ray order as node_step() / leaf_step() in csrc/kernels.hpp: a depth-first walk whose stack items are inner nodes AND
+// leaves.  At an inner node both child boxes are tested against the current tfar; of the hit children (leaf or not) the nearer
+// is visited next and the other pushed; a leaf is intersected when it is visited, then the next item is popped.  (The root box
+// itself is not tested.)
 static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz,
                                 float* tfar, int32_t* primID, LocalCounters& lc) {
 	bool fat;
@@ -864,25 +865,23 @@ static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims
 	uint32_t stack[64]; size_t sp = 0;
 	uint32_t id = 0;
 	for (;;) {
-		const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
-		float ta, tb;
-		lc.nodes += 2;
-		bool ha = slab_test(rs, bvh.padded[c0], *tfar, &ta);
-		bool hb = slab_test(rs, bvh.padded[c1], *tfar, &tb);
-		const bool la = bvh.nodes[c0].prim_count != 0, lb = bvh.nodes[c1].prim_count != 0;
-		if (ha && la) leaf(bvh.nodes[c0]);
-		if (hb && lb) leaf(bvh.nodes[c1]);
-		ha = ha && !la && ta <= *tfar;
-		hb = hb && !lb && tb <= *tfar;
-		if (ha && hb) {
-			const bool a_first = ta <= tb;
-			if (sp >= 64) abort();
-			stack[sp++] = a_first ? c1 : c0;
-			id = a_first ? c0 : c1;
-			continue;
+		if (bvh.nodes[id].prim_count != 0) leaf(bvh.nodes[id]);
+		else {
+			const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
+			float ta, tb;
+			lc.nodes += 2;
+			const bool ha = slab_test(rs, bvh.padded[c0], *tfar, &ta);
+			const bool hb = slab_test(rs, bvh.padded[c1], *tfar, &tb);
+			if (ha && hb) {
+				const bool a_first = ta <= tb;
+				if (sp >= 64) abort();
+				stack[sp++] = a_first ? c1 : c0;
+				id = a_first ? c0 : c1;
+				continue;
+			}
+			if (ha) { id = c0; continue; }
+			if (hb) { id = c1; continue; }
 		}
-		if (ha) { id = c0; continue; }
-		if (hb) { id = c1; continue; }
 		if (sp == 0) return;
 		id = stack[--sp];
 	}
@@ -911,24 +910,21 @@ static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>
 	uint32_t stack[64]; size_t sp = 0;
 	uint32_t id = 0;
 	for (;;) {
-		const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
-		float ta, tb;
-		lc.shadow_nodes += 2;
-		bool ha = slab_test(rs, bvh.padded[c0], tfar, &ta);
-		bool hb = slab_test(rs, bvh.padded[c1], tfar, &tb);
-		const bool la = bvh.nodes[c0].prim_count != 0, lb = bvh.nodes[c1].prim_count != 0;
-		// both hit leaf children are tested before the ray is declared finished, and the nearer inner child is entered first —
-		// the step order of trav_step<ANYHIT> in csrc/kernels.hpp.  Boxes per shadow ray, nearer-first vs storage order:
-		// S(1000) 40.4 vs 39.9, S(10000) 51.5 vs 54.5, S(100000) 61.1 vs 68.0 (the NEE rays of these scenes cross the sphere
-		// field towards one of a few lights and ~80 % are occluded somewhere along the way: the order matters more the deeper the tree).
-		bool occ = false;
-		if (ha && la) occ = leaf(bvh.nodes[c0]);
-		if (hb && lb) occ = leaf(bvh.nodes[c1]) || occ;
-		if (occ) return true;
-		ha = ha && !la; hb = hb && !lb;
-		if (ha && hb) { const bool a_first = ta <= tb; if (sp >= 64) abort(); stack[sp++] = a_first ? c1 : c0; id = a_first ? c0 : c1; continue; }
-		if (ha) { id = c0; continue; }
-		if (hb) { id = c1; continue; }
+		// the nearer hit child first, leaf or not (the order of node_step in csrc/kernels.hpp; any order gives the same answer).  Boxes
+		// per shadow ray, nearer-first vs storage order, measured with leaves tested inside the node step: S(1000) 40.4 vs 39.9,
+		// S(10000) 51.5 vs 54.5, S(100000) 61.1 vs 68.0 (the NEE rays of these scenes cross the sphere field towards one of a few
+		// lights and ~80 % are occluded somewhere along the way: the order matters more the deeper the tree).
+		if (bvh.nodes[id].prim_count != 0) { if (leaf(bvh.nodes[id])) return true; }
+		else {
+			const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
+			float ta, tb;
+			lc.shadow_nodes += 2;
+			const bool ha = slab_test(rs, bvh.padded[c0], tfar, &ta);
+			const bool hb = slab_test(rs, bvh.padded[c1], tfar, &tb);
+			if (ha && hb) { const bool a_first = ta <= tb; if (sp >= 64) abort(); stack[sp++] = a_first ? c1 : c0; id = a_first ? c0 : c1; continue; }
+			if (ha) { id = c0; continue; }
+			if (hb) { id = c1; continue; }
+		}
 		if (sp == 0) return false;
 		id = stack[--sp];
 	}
