@@ -52,6 +52,7 @@ struct SceneDev {
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
 	uint32_t chunk_max;         // rays per reservation from a launch's work counter, upper limit (pick_chunk)
 	uint32_t leaf_batch;        // lanes of a wave that must stand at a leaf before it runs a leaf pass (trace_persistent)
+	uint32_t refill_idle;       // idle lanes of a wave that trigger a refill (trace_persistent)
 	uint32_t stack16;           // 1: record and prim indices fit 15 bits and the LDS stack holds u16 entries (binary16 records, <= 32768 records and spheres)
 	float ambient[3];
 	int32_t hdri_w, hdri_h;
@@ -579,6 +580,9 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		// at least sc.leaf_batch lanes wait for one or no lane stands at a record, a NODE pass otherwise.  A waiting lane loses the
 		// node passes it sits out; the sphere test (~50 VALU instructions with its correctly rounded sqrt) runs at several times
 		// the lane density it had inside the node step.
+		// (Measured and dropped: SPECULATION — a lane parks the leaf it meets in a register and walks on until the wave's next leaf pass,
+		// so that node passes keep ~0.68 instead of ~0.61 of their lanes and leaf passes fill up.  The box tests made against the stale
+		// tfar cost more than that gains: 46 instead of 41 VALU wave-instructions per ray, k_trace 267 instead of 248 ms per cfg4 step.)
 		for (;;) {
 			const bool run = ri != kNone && !done;
 			const bool at_leaf = run & (static_cast<int32_t>(t.cur) < 0);            // kLeafBit is the sign bit
@@ -590,7 +594,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 			}
 			const unsigned long long running = __ballot(ri != kNone && !done);
 			if (running == 0ull) break;
-			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= kRefillIdle) break;
+			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= sc.refill_idle) break;
 		}
 	}
 }

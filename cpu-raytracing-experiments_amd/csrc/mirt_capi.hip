@@ -109,7 +109,7 @@ struct mirt_ctx {
 
 	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
 	// launch-shape knobs for measurements (profiles/experiments/*): MIRT_TUNE_TRACE_WGS / MIRT_TUNE_SHADE_WGS = workgroups per CU
-	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch;
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -391,7 +391,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	float* accum = contrib ? sl.contrib.as<float>() : c->accumulator.as<float>();
 	SceneDev sc = c->scene;
 	sc.use_bvh = c->policy.use_bvh;
-	sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch;
+	sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch; sc.refill_idle = c->tune_refill_idle;
 	const bool count = c->policy.count_traffic != 0;
 	const uint32_t tgrid = trace_grid(c, total);
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
@@ -500,6 +500,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	mirt_ctx* c = new mirt_ctx();
 	c->device = device;
 	if (const char* e = std::getenv("MIRT_TUNE_CHUNK")) c->tune_chunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 65536)) & ~63u;
+	if (const char* e = std::getenv("MIRT_TUNE_REFILL_IDLE")) c->tune_refill_idle = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
 	if (const char* e = std::getenv("MIRT_TUNE_LEAF_BATCH")) c->tune_leaf_batch = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
 	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
 	if (const char* e = std::getenv("MIRT_TUNE_SHADE_WGS")) c->tune_shade_wgs = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 16));
@@ -911,7 +912,7 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	HIP_TRY(c, hipMemcpy(cn, &n32, 4, hipMemcpyHostToDevice));                 // all n rays in segment 0 of the closest queue: slot = ray number
 	StreamBuf in{};
 	in.px = d; in.py = d + n; in.pz = d + 2 * n; in.dx = d + 3 * n; in.dy = d + 4 * n; in.dz = d + 5 * n;
-	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch;
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch; sc.refill_idle = c->tune_refill_idle;
 	DevCounters* scratch_ctr = nullptr;
 	HIP_TRY(c, ctr.ensure(sizeof(DevCounters))); scratch_ctr = ctr.as<DevCounters>();
 	HIP_TRY(c, hipMemset(scratch_ctr, 0, sizeof(DevCounters)));
@@ -947,7 +948,7 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	const uint32_t n32 = static_cast<uint32_t>(n);
 	HIP_TRY(c, hipMemcpy(cn + kQueueWords, &n32, 4, hipMemcpyHostToDevice));   // all n rays in segment 0 of the shadow queue
 	HIP_TRY(c, hipMemset(ctr.ptr, 0, sizeof(DevCounters)));
-	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch;
+	SceneDev sc = c->scene; sc.use_bvh = c->policy.use_bvh; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch; sc.refill_idle = c->tune_refill_idle;
 	ShadowBuf sh{}; sh.px = d; sh.py = d + n; sh.pz = d + 2 * n; sh.dx = d + 3 * n; sh.dy = d + 4 * n; sh.dz = d + 5 * n; sh.tfar = d + 6 * n;
 	uint32_t* misc = cn + 2 * kQueueWords;
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
@@ -991,7 +992,7 @@ int mirt_debug_primary_lists(mirt_ctx* c, uint32_t hist[10]) {
 	HIP_TRY(c, sync_all(c));
 	PipeSlot& sl = c->slots[0];
 	const FrameParams fp = frame_params(c, 0, 1);
-	SceneDev sc = c->scene; sc.use_bvh = 1; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch;
+	SceneDev sc = c->scene; sc.use_bvh = 1; sc.chunk_max = c->tune_chunk; sc.leaf_batch = c->tune_leaf_batch; sc.refill_idle = c->tune_refill_idle;
 	uint32_t* misc = sl.counts.as<uint32_t>();
 	HIP_TRY(c, hipMemsetAsync(misc, 0, 64, c->stream));
 	const float rho = bundle_half_angle(c);
