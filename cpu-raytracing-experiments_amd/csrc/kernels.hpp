@@ -297,6 +297,20 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 // Select-only forms of the two sphere tests for the traversal loop (same arithmetic and acceptance as sphere_closest /
 // sphere_occludes above; a divergent branch costs several scalar exec-mask instructions, and the CU's single scalar unit
 // was issuing as many instructions as its four SIMDs).
+// sqrt of the two tests below: correctly rounded, bit for bit __builtin_sqrtf (hipcc's expansion around v_sqrt_f32: one fix-up step
+// towards each neighbour, decided by an FMA residual) WITHOUT that expansion's seven instructions of denormal scaling and 0 / inf
+// pass-through, which only inputs outside [2^-100, 2^100) need; a wave that holds such a discriminant (none in practice) takes the
+// library path as a whole.  Negative and NaN inputs give a NaN-or-garbage that both callers mask.  Checked against __builtin_sqrtf
+// for every f32 in the range by profiles/experiments/sqrt_check.hip and by tests (mirt_debug_math fn 10).
+MIRT_DI float sqrt_trav(float x) {
+	if (__ballot((x >= 0.0f) & !((x >= 0x1p-100f) & (x < 0x1p100f))) != 0ull) return __builtin_sqrtf(x);
+	const float s = __builtin_amdgcn_sqrtf(x);                                // within 1 ulp
+	const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+	const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+	float r = (r_dn <= 0.0f) ? s_dn : s;
+	r = (r_up > 0.0f) ? s_up : r;
+	return r;
+}
 MIRT_DI void sphere_closest_sel(bool lane_on, float4 s, int32_t prim, const float px, const float py, const float pz, const float dx, const float dy,
                                 const float dz, float& tfar, int32_t& primID) {
 	const float tx = s.x - px;
@@ -310,7 +324,7 @@ MIRT_DI void sphere_closest_sel(bool lane_on, float4 s, int32_t prim, const floa
 	disc = __builtin_fmaf(-tz, tz, disc);
 	disc = __builtin_fmaf(b, b, disc);
 	const bool disc_ok = !(__float_as_uint(disc) & 0x80000000u);
-	const float sq = __builtin_sqrtf(disc);                       // NaN for a negative discriminant: masked by disc_ok
+	const float sq = sqrt_trav(disc);                             // NaN for a negative discriminant: masked by disc_ok
 	float dist = b - sq;
 	dist = (__float_as_uint(dist) & 0x80000000u) ? b + sq : dist;
 	// bitwise &,| on purpose: short-circuit &&,|| come back as nested exec-mask branches
@@ -323,7 +337,7 @@ MIRT_DI bool sphere_occludes_sel(float4 s, const float px, const float py, const
 	const f3 P{ s.x - px, s.y - py, s.z - pz };
 	const float b = dot3(f3{ dx, dy, dz }, P);
 	const float disc = b * b - dot3(P, P) + s.w;
-	const float sq = __builtin_sqrtf(disc);
+	const float sq = sqrt_trav(disc);
 	const float dist = (b >= sq ? b - sq : b + sq);
 	return !(disc < 0.0f) & !((dist < 0.0f) | (dist >= tfar));
 }
@@ -1289,6 +1303,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_math(int fn, uint32_t n, const
 			out[3 * n + i] = rand_unit_float(s);
 			out[4 * n + i] = __uint_as_float(rand_bounded_int(s2, __float_as_uint(in[2 * n + i])));
 		} break;
+		case 10: out[i] = sqrt_trav(in[i]); break;
 		case 8: {   // Closure<GGX>::eval: in F0(3), alpha, L(3), V(3) -> out 3
 			const f3 r = ggx_eval(f3{ in[i], in[n + i], in[2 * n + i] }, in[3 * n + i], f3{ in[4 * n + i], in[5 * n + i], in[6 * n + i] }, f3{ in[7 * n + i], in[8 * n + i], in[9 * n + i] });
 			out[i] = r.x; out[n + i] = r.y; out[2 * n + i] = r.z;

@@ -968,8 +968,8 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 
 int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) {
 	if (!c) return MIRT_ERR_ARG;
-	static const int n_in[10] = { 1, 2, 1, 2, 2, 6, 8, 3, 10, 9 }, n_out[10] = { 2, 1, 1, 3, 3, 10, 5, 5, 3, 6 };
-	if (fn < 0 || fn > 9 || !in || !out || n == 0 || n >= (1u << 28)) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	static const int n_in[11] = { 1, 2, 1, 2, 2, 6, 8, 3, 10, 9, 1 }, n_out[11] = { 2, 1, 1, 3, 3, 10, 5, 5, 3, 6, 1 };
+	if (fn < 0 || fn > 10 || !in || !out || n == 0 || n >= (1u << 28)) return fail(c, MIRT_ERR_ARG, "bad arguments");
 	HIP_TRY(c, hipSetDevice(c->device));
 	ScopedBuffer din, dout;
 	HIP_TRY(c, din.ensure(n * n_in[fn] * 4)); HIP_TRY(c, dout.ensure(n * n_out[fn] * 4));

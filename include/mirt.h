@@ -251,6 +251,7 @@ int mirt_debug_trace_shadow(mirt_ctx* ctx, size_t n, const float* p_xyz, const f
  *     7 rng: hash_2d(x,y) then 3 pcg draws as float + bounded int  [Random.hpp:5-50]  in: x[n],y[n],range[n] as u32 bits  out: 5n (hash bits, f0,f1,f2, bounded bits)
  *     8 Closure<GGX>::eval         [DataStreams.hpp:189-195, Sampling.hpp:272-296]  in: F0(3n),alpha[n],Llocal(3n),Vlocal(3n)  out: 3n
  *     9 Closure<GGX>::sample       [DataStreams.hpp:200-218, Sampling.hpp:254-270,297-309]  in: F0(3n),alpha[n],Vlocal(3n),u0[n],u1[n]  out: 6n (dir, estimator)
+ *    10 the sphere tests' sqrt (kernels.hpp sqrt_trav) — must equal IEEE sqrt for every input >= 0   in: x[n]  out: n
  *       (8, 9: the defined part of the reference's compiled-out GGX closure; not used by the path — DESIGN.md §7)
  */
 int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out);

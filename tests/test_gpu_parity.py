@@ -62,6 +62,12 @@ def test_device_math_bit_exact(mirt, gpu, oracle_lib):
         assert_same(out[0], np.float32(1.0) / a, "1/x")
         assert_same(out[1], np.sqrt(np.abs(a)), "sqrt")
         assert_same(out[2], a / b, "a/b")
+    # the traversal's own sqrt (kernels.hpp sqrt_trav: hipcc's correctly rounded expansion minus its denormal scaling) is IEEE sqrt
+    # wherever the sphere tests use it (inputs >= 0; every bit pattern: profiles/experiments/sqrt_check.hip)
+    xs = np.concatenate([np.exp(rng.uniform(-80, 80, n)), rng.uniform(0, 4, n), (np.arange(1, 4097, dtype=np.float64) / 64.0) ** 2,
+                         [0.0, 1e-45, 1e-40, 1.1754944e-38, 7e-31, 8e-31, 1.2e30, 1.3e30, 3.4e38, np.inf, 1.0, 4.0, 2.0]]).astype(np.float32)
+    got = gpu.debug_math(10, xs[None, :], 1)
+    assert_same(got[0], np.sqrt(xs), "sqrt_trav")
     # hemisphere, tangent frame, light sampling
     t = rng.uniform(0, 1, n).astype(np.float32); u = rng.uniform(0, 1, n).astype(np.float32)
     t[:2] = [1.0, 0.0]
