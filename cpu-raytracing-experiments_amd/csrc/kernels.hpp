@@ -594,6 +594,9 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		// at least sc.leaf_batch lanes wait for one or no lane stands at a record, a NODE pass otherwise.  A waiting lane loses the
 		// node passes it sits out; the sphere test (~50 VALU instructions with its correctly rounded sqrt) runs at several times
 		// the lane density it had inside the node step.
+		// (Measured and dropped: REQUESTING THE NEXT RECORD EARLY — as soon as a lane knows its next node, into two register quads
+		// live across the passes: 51 VGPR spills around the loop and k_trace 249 -> 276 ms per cfg4 step; the other seven waves of
+		// the SIMD already cover the load at the head of each pass.)
 		// (Measured and dropped: SPECULATION — a lane parks the leaf it meets in a register and walks on until the wave's next leaf pass,
 		// so that node passes keep ~0.68 instead of ~0.61 of their lanes and leaf passes fill up.  The box tests made against the stale
 		// tfar cost more than that gains: 46 instead of 41 VALU wave-instructions per ray, k_trace 267 instead of 248 ms per cfg4 step.)
