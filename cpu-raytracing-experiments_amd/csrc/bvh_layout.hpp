@@ -168,7 +168,7 @@ inline std::string build_records(const mirt_bvh_node* nodes, uint32_t n_nodes, c
 	recs.clear();
 	*max_depth_out = 0;
 	if (n_nodes == 0) return "";
-	if (n_prims >= (1u << 31)) return "more than 2^31 spheres";
+	if (n_prims >= (1u << 26)) return "more than 2^26 spheres";       // record byte offsets are 32-bit in the trace kernels, leaf references carry a flag bit
 	// conservative boxes, children before parents (children always have larger indices; validated by the caller)
 	std::vector<PadBox> box(n_nodes);
 	for (uint32_t k = n_nodes; k-- > 0;) {

@@ -432,9 +432,10 @@ MIRT_DI uint32_t stack_get(const TraceLds lds, const TravSpill& spill, uint32_t 
 // (leaf_step: intersect its sphere, then pop).  The two kinds of step are separate so that a wave can run them as separate,
 // DENSE passes (trace_persistent): with the sphere test inlined in the node step, as it was, ~58 % of the loop's VALU
 // instructions were sphere tests executed for the whole wave on behalf of the ~13 % of lanes that had a hit leaf in that step.
-// Both return true when this ray is finished (stack empty, or ANYHIT occluder found -> occluded = true, or a full kCollect list).
+// Both leave t.cur = kHalt when this ray is finished (stack empty, or ANYHIT occluder found -> occluded = true, or a full kCollect list).
+constexpr uint32_t kHalt = 0x7fffffffu;         // Trav::cur of a lane that is not walking: no ray, or a finished one whose result waits for the next refill
 template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
-MIRT_DI bool node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, uint32_t& n_nodes) {
+MIRT_DI void node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, uint32_t& n_nodes) {
 	const uint32_t cur = t.cur;
 	// child boxes: (lo, hi) per axis for child 0 (a) and child 1 (b)
 	float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
@@ -445,7 +446,7 @@ MIRT_DI bool node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		// any other step reads every lane's record from memory (the top records are the hottest lines of L1 / L2) — one path per step
 		// instead of two exec-masked halves.
 		if (ALL_LDS || __ballot(cur >= sc.lds_recs) == 0ull) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
-		else { const v4f* r = reinterpret_cast<const v4f*>(sc.recs) + 2ull * cur; q0 = r[0]; q1 = r[1]; }
+		else { const v4f* r = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(sc.recs) + (cur << 5)); q0 = r[0]; q1 = r[1]; }   // 32-bit byte offset from a uniform base (n_recs < 2^27, checked on the host)
 		const uint32_t w0 = __float_as_uint(q0.x), w1 = __float_as_uint(q0.y), w2 = __float_as_uint(q0.z), w3 = __float_as_uint(q0.w);
 		const uint32_t w4 = __float_as_uint(q1.x), w5 = __float_as_uint(q1.y);
 		ax0 = half_lo(w0); bx0 = half_hi(w0); ax1 = half_lo(w1); bx1 = half_hi(w1);
@@ -480,15 +481,13 @@ MIRT_DI bool node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	const uint32_t far = a_first ? c1 : c0;
 	uint32_t sp = t.sp;
 	if (both) { stack_put<HALF, ST16>(lds, spill, sp, far); sp += 1u; }
-	uint32_t next = near;
-	const bool pop = none & (sp != 0u);
-	if (pop) { --sp; next = stack_get<HALF, ST16>(lds, spill, sp); }
+	uint32_t next = none ? kHalt : near;                                     // nothing hit and nothing stacked: finished
+	if (none & (sp != 0u)) { --sp; next = stack_get<HALF, ST16>(lds, spill, sp); }
 	t.sp = sp;
 	t.cur = next;
-	return none & !pop;
 }
 template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
-MIRT_DI bool leaf_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_spheres, uint32_t pix, const Collect& col) {
+MIRT_DI void leaf_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_spheres, uint32_t pix, const Collect& col) {
 	const uint32_t first = t.cur & ~kLeafBit;
 	// (Requesting the sphere when the lane ARRIVES at the leaf, into four registers kept until the pass, was measured: 22 VGPR
 	// spills and k_trace 253 -> 283 ms per cfg4 step.  The other seven waves of the SIMD cover this load.)
@@ -500,10 +499,9 @@ MIRT_DI bool leaf_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	else if (MODE == kCollect) { collect_leaf(true, s, first, pix, col, t); fin = static_cast<uint32_t>(t.prim) > kCandMax; }   // a full list: the pixel falls back to tracing
 	else sphere_closest_sel(true, s, static_cast<int32_t>(first), t.px, t.py, t.pz, t.dx, t.dy, t.dz, t.tfar, t.prim);
 	uint32_t sp = t.sp;
-	const bool pop = !fin & (sp != 0u);
-	if (pop) { --sp; t.cur = stack_get<HALF, ST16>(lds, spill, sp); }
+	t.cur = kHalt;
+	if (!fin & (sp != 0u)) { --sp; t.cur = stack_get<HALF, ST16>(lds, spill, sp); }
 	t.sp = sp;
-	return !pop;
 }
 
 // ---- persistent waves with in-kernel lane refill ------------------------------------------------------------
@@ -555,7 +553,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n,
 }
 
 // Persistent wave loop shared by the closest-hit and the any-hit kernels.
-//   * a lane is RUNNING (ri != kNone, !done), DONE (result waiting to be flushed) or EMPTY;
+//   * a lane is WALKING (t.cur is a record or a leaf), DONE (ri != kNone, t.cur == kHalt: result waiting to be flushed) or EMPTY (ri == kNone);
 //   * a refill event (>= kRefillIdle lanes not running) flushes the finished lanes' results, hands the idle lanes the next
 //     ray indices of the window and loads + sets up their rays — all as batched, mostly coalesced accesses.  (An earlier
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
@@ -567,10 +565,11 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 	Trav t;
 	TravSpill spill;
 	uint32_t ri = kNone;
-	bool done = false, occluded = false;
+	bool occluded = false;
+	t.cur = kHalt;
 	for (;;) {
 		// ---- refill event: flush results, hand the idle lanes the next ray indices of the window, load and set up their rays ----
-		if (done) { store_result(ri, t, occluded); done = false; ri = kNone; }
+		if ((ri != kNone) & (t.cur == kHalt)) { store_result(ri, t, occluded); ri = kNone; }
 		{
 			const uint32_t got = wave_take(ri == kNone, w, q, n, work_next);   // a slot of the stream planes
 			if (got != kNone) {
@@ -578,22 +577,22 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 				load_ray(got, px, py, pz, dx, dy, dz, tf);
 				ri = got; occluded = false;
 				if (MODE == kCollect) {
-					if (trav_begin(t, px, py, pz, dx, dy, dz, tf, col.rho)) { t.prim = static_cast<int32_t>(kCandMax + 1u); done = true; }   // a bundle too wide for the tree: the pixel is traced normally
+					if (trav_begin(t, px, py, pz, dx, dy, dz, tf, col.rho)) { t.prim = static_cast<int32_t>(kCandMax + 1u); t.cur = kHalt; }   // a bundle too wide for the tree: the pixel is traced normally
 					else t.prim = 0;                                           // candidates listed so far
 				} else if (trav_begin(t, px, py, pz, dx, dy, dz, tf)) {
 					const uint32_t k = atomicAdd(fat.count, 1u);               // rare: a few rays per million
-					if (k < fat.capacity) { fat.rays[k] = got; ri = kNone; }   // list full -> traverse it after all (correct, only slow)
+					if (k < fat.capacity) { fat.rays[k] = got; ri = kNone; t.cur = kHalt; }   // list full -> traverse it after all (correct, only slow)
 				}
 			}
 		}
 		const bool work_left = w.more || w.beg != w.chunk_end;
 		if (__ballot(ri != kNone) == 0ull) { if (!work_left) break; continue; }
 		const bool can_refill = work_left;
-		// ---- step every running lane until enough lanes have finished to make the next refill worthwhile ----
-		// One pass per iteration, chosen for the whole wave: a LEAF pass (the lanes standing at a leaf intersect their sphere) once
-		// at least sc.leaf_batch lanes wait for one or no lane stands at a record, a NODE pass otherwise.  A waiting lane loses the
-		// node passes it sits out; the sphere test (~50 VALU instructions with its correctly rounded sqrt) runs at several times
-		// the lane density it had inside the node step.
+		// ---- step every walking lane until enough lanes have finished to make the next refill worthwhile ----
+		// A lane's state is its t.cur: a record index (at a node), kLeafBit | prim (at a leaf) or kHalt.  One pass per iteration, chosen
+		// for the whole wave: a LEAF pass (the lanes standing at a leaf intersect their sphere) once at least sc.leaf_batch lanes wait
+		// for one or no lane stands at a record, a NODE pass otherwise.  A waiting lane loses the node passes it sits out; the sphere
+		// test (~50 VALU instructions with its correctly rounded sqrt) runs at several times the lane density it had inside the node step.
 		// (Measured and dropped: REQUESTING THE NEXT RECORD EARLY — as soon as a lane knows its next node, into two register quads
 		// live across the passes: 51 VGPR spills around the loop and k_trace 249 -> 276 ms per cfg4 step; the other seven waves of
 		// the SIMD already cover the load at the head of each pass.)
@@ -601,17 +600,16 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		// so that node passes keep ~0.68 instead of ~0.61 of their lanes and leaf passes fill up.  The box tests made against the stale
 		// tfar cost more than that gains: 46 instead of 41 VALU wave-instructions per ray, k_trace 267 instead of 248 ms per cfg4 step.)
 		for (;;) {
-			const bool run = ri != kNone && !done;
-			const bool at_leaf = run & (static_cast<int32_t>(t.cur) < 0);            // kLeafBit is the sign bit
-			const unsigned long long leaf_m = __ballot(at_leaf), node_m = __ballot(run & !at_leaf);
+			const bool at_leaf = static_cast<int32_t>(t.cur) < 0, at_node = t.cur < kHalt;      // kLeafBit is the sign bit
+			const unsigned long long leaf_m = __ballot(at_leaf), node_m = __ballot(at_node);
+			const unsigned long long walking = leaf_m | node_m;
+			if (walking == 0ull) break;
+			if (can_refill && 64u - static_cast<uint32_t>(__popcll(walking)) >= sc.refill_idle) break;
 			if (node_m == 0ull || static_cast<uint32_t>(__popcll(leaf_m)) >= sc.leaf_batch) {
-				if (at_leaf) done = leaf_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_spheres, ri, col);
+				if (at_leaf) leaf_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_spheres, ri, col);
 			} else {
-				if (run & !at_leaf) done = node_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, c_nodes);
+				if (at_node) node_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, c_nodes);
 			}
-			const unsigned long long running = __ballot(ri != kNone && !done);
-			if (running == 0ull) break;
-			if (can_refill && 64u - static_cast<uint32_t>(__popcll(running)) >= sc.refill_idle) break;
 		}
 	}
 }

@@ -543,6 +543,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	if (!c) return MIRT_ERR_ARG;
 	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	if (n_spheres && (!geometry || !bvh_prims)) return fail(c, MIRT_ERR_ARG, "geometry / bvh_prims is NULL");
+	if (n_spheres >= (1u << 26)) return fail(c, MIRT_ERR_ARG, "more than 2^26 spheres");      // 32-bit record offsets in the trace kernels (GPU-built trees do not pass build_records)
 	if (n_nodes && !nodes) return fail(c, MIRT_ERR_ARG, "nodes is NULL");
 	if (!materials || n_materials == 0 || n_materials > MIRT_MAX_MATERIALS) return fail(c, MIRT_ERR_ARG, "need 1..%u materials, got %u", MIRT_MAX_MATERIALS, n_materials);
 	if (n_lights && !lights) return fail(c, MIRT_ERR_ARG, "lights is NULL");
