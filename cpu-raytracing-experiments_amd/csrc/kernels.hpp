@@ -274,7 +274,9 @@ MIRT_DI bool slab_hit(const RaySlab& rs, float lx, float hx, float ly, float hy,
 	const float ex = __builtin_amdgcn_fmed3f(lx, hx, rs.cx), ey = __builtin_amdgcn_fmed3f(ly, hy, rs.cy), ez = __builtin_amdgcn_fmed3f(lz, hz, rs.cz);
 	const float ox = __builtin_fmaxf(__builtin_fmaxf(lx, hx), rs.cx), oy = __builtin_fmaxf(__builtin_fmaxf(ly, hy), rs.cy), oz = __builtin_fmaxf(__builtin_fmaxf(lz, hz), rs.cz);
 	const float tmin = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 0.0f));
-	const float tmax = __builtin_fminf(__builtin_fminf(ox, oy), __builtin_fminf(oz, tfar));
+	float oz_far;                                                             // min(oz, tfar) as the bare instruction: __builtin_fminf first canonicalises tfar (a v_max_f32 x, x per step) in case it were a signalling NaN
+	asm("v_min_f32 %0, %1, %2" : "=v"(oz_far) : "v"(oz), "v"(tfar));
+	const float tmax = __builtin_fminf(__builtin_fminf(ox, oy), oz_far);
 	tnear = tmin;
 	return tmin <= tmax;
 }
@@ -299,11 +301,13 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 // was issuing as many instructions as its four SIMDs).
 // sqrt of the two tests below: correctly rounded, bit for bit __builtin_sqrtf (hipcc's expansion around v_sqrt_f32: one fix-up step
 // towards each neighbour, decided by an FMA residual) WITHOUT that expansion's seven instructions of denormal scaling and 0 / inf
-// pass-through, which only inputs outside [2^-100, 2^100) need; a wave that holds such a discriminant (none in practice) takes the
-// library path as a whole.  Negative and NaN inputs give a NaN-or-garbage that both callers mask.  Checked against __builtin_sqrtf
-// for every f32 in the range by profiles/experiments/sqrt_check.hip and by tests (mirt_debug_math fn 10).
+// pass-through.  Only inputs in [+0, 2^-100) need the scaling (their residuals would be denormal); a wave that holds such a
+// discriminant (none in practice) takes the library path as a whole — one unsigned compare on the bits, which negative inputs
+// pass.  +inf and the large values fall out right (NaN residuals select nothing); negative and NaN inputs give NaN-or-garbage that
+// both callers mask.  Checked against __builtin_sqrtf for EVERY f32 bit pattern >= 0 by profiles/experiments/sqrt_check.hip, and
+// by tests (mirt_debug_math fn 10).
 MIRT_DI float sqrt_trav(float x) {
-	if (__ballot((x >= 0.0f) & !((x >= 0x1p-100f) & (x < 0x1p100f))) != 0ull) return __builtin_sqrtf(x);
+	if (__ballot(__float_as_uint(x) < 0x0d800000u) != 0ull) return __builtin_sqrtf(x);     // 0x0d800000 = 2^-100
 	const float s = __builtin_amdgcn_sqrtf(x);                                // within 1 ulp
 	const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
 	const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
@@ -475,9 +479,9 @@ MIRT_DI void node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	                         __builtin_fmaf(by0, rs.iay, rs.nay), __builtin_fmaf(by1, rs.iby, rs.nby),
 	                         __builtin_fmaf(bz0, rs.iaz, rs.naz), __builtin_fmaf(bz1, rs.ibz, rs.nbz), t.tfar, tb);
 	// ---- next item: selects, plus one exec region each for the conditional stack write and read ----
-	const bool both = ha & hb, none = !(ha | hb);
+	const bool both = ha && hb, none = !ha && !hb;
 	const bool a_first = ta <= tb;                                            // any-hit rays too: an occluder is most likely close to the origin (the result does not depend on the order)
-	const uint32_t near = (ha & (a_first | !hb)) ? c0 : c1;                   // the child entered when at least one child is hit
+	const uint32_t near = (ha && (a_first || !hb)) ? c0 : c1;                 // the child entered when at least one child is hit
 	const uint32_t far = a_first ? c1 : c0;
 	uint32_t sp = t.sp;
 	if (both) { stack_put<HALF, ST16>(lds, spill, sp, far); sp += 1u; }

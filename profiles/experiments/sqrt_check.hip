@@ -14,7 +14,7 @@ __global__ void k(unsigned long long* bad, unsigned long long* slow, uint32_t* f
 		const float want = __builtin_sqrtf(x), got = mirt::sqrt_trav(x);
 		const bool in_domain = x >= 0.0f;                                   // callers mask x < 0 and NaN
 		if (in_domain && __float_as_uint(want) != __float_as_uint(got)) { b++; atomicMin(first_bad, i); }
-		if (in_domain && !((x >= 0x1p-100f) & (x < 0x1p100f))) sl++;
+		if (in_domain && __float_as_uint(x) < 0x0d800000u) sl++;
 	}
 	atomicAdd(bad, b); atomicAdd(slow, sl);
 }
@@ -23,6 +23,6 @@ int main() {
 	(void)hipMalloc(&d, 16); (void)hipMalloc(&fb, 4); (void)hipMemcpy(d, h, 16, hipMemcpyHostToDevice); (void)hipMemcpy(fb, &hfb, 4, hipMemcpyHostToDevice);
 	hipLaunchKernelGGL(k, dim3(4096), dim3(256), 0, 0, d, d + 1, fb);
 	(void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost); (void)hipMemcpy(&hfb, fb, 4, hipMemcpyDeviceToHost);
-	printf("sqrt_trav vs __builtin_sqrtf over all 2^32 bit patterns: %llu mismatches among inputs >= 0 (first at bits 0x%08x); %llu inputs outside [2^-100, 2^100) took the library path\n", h[0], hfb, h[1]);
+	printf("sqrt_trav vs __builtin_sqrtf over all 2^32 bit patterns: %llu mismatches among inputs >= 0 (first at bits 0x%08x); %llu inputs in [+0, 2^-100) took the library path\n", h[0], hfb, h[1]);
 	return h[0] != 0;
 }
