@@ -449,7 +449,7 @@ MIRT_DI void node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 		// Only the top of a large tree is staged.  The choice is made per WAVE: a step whose lanes are all in the staged block reads LDS,
 		// any other step reads every lane's record from memory (the top records are the hottest lines of L1 / L2) — one path per step
 		// instead of two exec-masked halves.
-		if (ALL_LDS || __ballot(cur >= sc.lds_recs) == 0ull) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
+		if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + cur; q0 = r[0]; q1 = r[sc.lds_recs]; }     // plane-major in LDS
 		else { const v4f* r = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(sc.recs) + (cur << 5)); q0 = r[0]; q1 = r[1]; }   // 32-bit byte offset from a uniform base (n_recs < 2^27, checked on the host)
 		const uint32_t w0 = __float_as_uint(q0.x), w1 = __float_as_uint(q0.y), w2 = __float_as_uint(q0.z), w3 = __float_as_uint(q0.w);
 		const uint32_t w4 = __float_as_uint(q1.x), w5 = __float_as_uint(q1.y);
