@@ -129,7 +129,8 @@ def collect_pmc(args, log):
         return None
     out["sq"], out["child"] = sq
     # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes; GRBM: the clock the chip held; then the VALU instruction mix
-    for name, counters in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("mix", MIX_COUNTERS)):
+    for name, counters in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("mix", MIX_COUNTERS),
+                           ("vmem", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE")):
         r = run_pmc_pass(counters, args, log)
         out[name] = r[0] if r else None
     log(f"pmc passes took {time.perf_counter() - t0:.1f}s")
@@ -379,6 +380,17 @@ def main():
                     ghz = gr["trace"]["GRBM_GUI_ACTIVE"] / 8.0 / (gr["trace"]["us"] * 1e-6) / 1e9
                     roofline["clock_GHz_during_k_trace"] = ghz
                     roofline["frac_at_that_clock"] = (ach / (256 * 4 * ghz)) if ach else None
+                vm = (pmc.get("vmem") or {}).get("trace")
+                if vm and vm.get("GRBM_GUI_ACTIVE"):
+                    # the second unit k_trace leans on: every lane of a node / leaf pass gathers its own 32-B record or 16-B sphere, and a CU's
+                    # L1 (TCP) takes about one cache-line access per cycle.  GRBM_GUI_ACTIVE is summed over the 8 XCDs -> CU-cycles = x 32.
+                    cu_cycles = vm["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
+                    roofline["vector_memory"] = {"l1_line_accesses_per_cu_cycle": vm["TCP_TOTAL_CACHE_ACCESSES_sum"] / cu_cycles,
+                                                 "l1_miss_share": vm["TCP_TCC_READ_REQ_sum"] / max(vm["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0),
+                                                 "ta_busy_share": vm["TA_TA_BUSY_sum"] / cu_cycles,
+                                                 "l1_line_accesses_per_traced_ray": vm["TCP_TOTAL_CACHE_ACCESSES_sum"] / ch_traced,
+                                                 "note": "TCP_TOTAL_CACHE_ACCESSES_sum, TCP_TCC_READ_REQ_sum, TA_TA_BUSY_sum over the k_trace dispatches of the PMC child batch, "
+                                                         "per CU-cycle (GRBM_GUI_ACTIVE / 8 x 256 CUs)"}
                 f, w_ = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
                 if f and w_ and "trace" in f and "trace" in w_:
                     # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact; both in KB
