@@ -115,7 +115,7 @@ inline void split_multi_prim_leaves(std::vector<mirt_bvh_node>& nodes) {
 
 // 32-B half-precision records from the 64-B ones.  Returns false (and leaves `out` empty) when binary16 is not adequate:
 // a coordinate beyond +-60000, or a leaf box whose smallest extent is under 8 quantisation steps (the box would grow by
-// more than ~25 %).  (With more than 65535 records the traversal stack keeps u32 entries, see mirt_capi.hip.)
+// more than ~25 %).  (With more than 32768 records or spheres the traversal stack keeps u32 entries, see mirt_capi.hip.)
 inline bool build_half_records(const std::vector<float>& recs, std::vector<uint32_t>& out) {
 	out.clear();
 	const size_t n = recs.size() / 16;

@@ -30,7 +30,7 @@ constexpr uint32_t kBlock = 256;
 constexpr uint32_t kShadeBlock = 512;           // shade: 73-79 VGPRs = 24 waves per CU = three 8-wave workgroups (forced to 64 VGPRs for a fourth: 15-20 spills, 92 -> 109 ms per cfg4 step; 1024-thread workgroups: one per CU, every barrier stalls the CU)
 constexpr uint32_t kTraceBlock = 1024;          // trace kernels: one workgroup per CU stages the BVH into LDS once per launch
 constexpr uint32_t kLdsStack = 16;              // traversal-stack entries per lane kept in LDS (deeper ones spill to scratch)
-constexpr uint32_t kLdsStackWide = 12;          // ... with binary16 records but u32 entries (> 65535 records): 48 KB, so that two workgroups still share a CU
+constexpr uint32_t kLdsStackWide = 12;          // ... with binary16 records but u32 entries (> 32768 records or spheres): 48 KB, so that two workgroups still share a CU
 constexpr uint32_t kLeafBit = 0x80000000u;      // child reference flag (bvh_layout.hpp)
 constexpr uint32_t kTileSize = 256;
 constexpr uint32_t kTileRoot = 16;
@@ -735,7 +735,7 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, 
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
 	if (sc.half_boxes) {
-		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 65535 records: never all in LDS
+		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 32768 records or spheres: never all in LDS
 		else if (all) trace_persistent<MODE, COUNT, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 		else trace_persistent<MODE, COUNT, false, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 	} else {

@@ -165,7 +165,7 @@ uint32_t grid_for(const mirt_ctx* c, uint64_t work_items) {
 // CU hold) and grid-stride over the stream, so each workgroup stages the BVH into LDS once per launch.
 constexpr uint32_t kLdsPerCu = 160u * 1024u;
 // LDS plan of a trace workgroup (1024 lanes): staged BVH bytes + a per-lane traversal stack.
-//   binary16 records, <= 65535 of them: 16 u16 entries (32 KB) + up to 48 KB staged  -> TWO workgroups (32 waves) per CU
+//   binary16 records, <= 32768 records and spheres: 16 u16 entries (32 KB) + up to 48 KB staged  -> TWO workgroups (32 waves) per CU
 //   binary16 records, more of them:     12 u32 entries (48 KB) + up to 32 KB staged  -> two workgroups per CU
 //   f32 records:                        16 u32 entries (64 KB) + up to 96 KB staged  -> one workgroup per CU
 uint32_t stack_bytes(bool half, bool stack16) { return half ? (stack16 ? kLdsStack * kTraceBlock * 2u : kLdsStackWide * kTraceBlock * 4u) : kLdsStack * kTraceBlock * 4u; }

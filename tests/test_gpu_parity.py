@@ -260,6 +260,46 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     r.close()
 
 
+def test_deep_stack_and_wide_references(mirt):
+    """Two corners of the traversal stack (kernels.hpp stack_put / stack_get): (1) a caller's chain-shaped tree over spheres lined up
+    behind each other, ordered so that every camera ray enters the nearer inner child and stacks the farther LEAF at every level —
+    47 entries deep, far past the 12-16 entries kept in LDS, through the scratch spill; (2) a scene of 40 000 spheres, where record
+    and prim indices no longer fit the 15 + 1 bits of the u16 stack entries and the u32 stack is used with binary16 records."""
+    n = 48
+    sc = mirt.scene.synthetic(n, ambient=0.5)
+    sc.geometry["position"] = np.stack([np.zeros(n), np.zeros(n), -3.0 * np.arange(n)], axis=1).astype(np.float32)
+    sc.geometry["radius_sq"] = np.float32(1.0)
+    sc.camera = mirt.scene.Camera(eye=(0.0, 0.0, 12.0), direction=(0.0, 0.0, -1.0), focal_length=200.0, exposure=1.0)
+    o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(64, 48); o.Accumulate(5)
+    for primary in (True, False):
+        r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, reference_tree=True, count_traffic=True, trace_primary_rays=primary)
+        slot_z = r.prims["position"][:, 2]
+        order = np.argsort(slot_z)                                   # farthest slot first: leaf k of the chain is the farthest sphere left
+        chain = np.zeros(2 * n - 1, dtype=mirt.scene.NODE)
+        chain["min_bound"] = [-1.0, -1.0, slot_z.min() - 1.0]; chain["max_bound"] = [1.0, 1.0, slot_z.max() + 1.0]      # (the product derives its own boxes)
+        for k in range(n - 1):                                       # inner node 2k -> children 2k+1 (leaf) and 2k+2 (the rest: inner, or the last leaf)
+            chain["first_id"][2 * k] = 2 * k + 1; chain["prim_count"][2 * k] = 0
+            chain["first_id"][2 * k + 1] = order[k]; chain["prim_count"][2 * k + 1] = 1
+        chain["first_id"][2 * n - 2] = order[n - 1]; chain["prim_count"][2 * n - 2] = 1
+        r.UpdateScene(nodes=chain)
+        assert r.debug_info()["depth"] >= n
+        r.Resize(64, 48); r.Accumulate(5)
+        assert_same(r.accumulator(), o.accumulator(), f"chain tree, stack {n - 1} deep (trace_primary_rays={primary})")
+        c = r.counters()
+        assert c["rays"] == o.counters()["rays"] and c["nodes"] > 2 * (n - 1) * 64 * 48      # the camera rays alone walk the whole chain
+        r.close()
+    big = mirt.scene.synthetic(40000)
+    r = mirt.Renderer(big, max_bounces=4, use_bvh=True, count_traffic=True, trace_primary_rays=True); r.Resize(64, 48); r.Accumulate(5)
+    info = r.debug_info()
+    assert info["half_boxes"] == 1 and info["records"] == 39999 and info["lds_records"] == 1024          # 32 KB of staged records: the u32-stack plan
+    t = ob.Oracle(big, max_bounces=4, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(64, 48); t.Accumulate(5)
+    assert_same(r.accumulator(), t.accumulator(), "S(40000) vs the twin")
+    cg, ct = r.counters(), t.counters()
+    for k in ("rays", "nodes", "spheres", "shadow_rays", "shadow_nodes", "shadow_spheres"):
+        assert cg[k] == ct[k], k
+    r.close()
+
+
 @pytest.mark.parametrize("scene_name,allow_half,w,h,spp,mb", [("default9", True, 64, 64, 5, 16), ("S8a", True, 64, 64, 5, 5), ("S1000a", True, 128, 128, 5, 5),
                                                              ("S1000a", False, 128, 128, 5, 5), ("S20000", True, 256, 128, 5, 6)])
 def test_gpu_built_tree_gives_the_same_results(mirt, scene_name, allow_half, w, h, spp, mb):
