@@ -1049,14 +1049,24 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	for (uint32_t m = threadIdx.x; m < sc.n_mat; m += kShadeBlock) { s_albedo[m] = sc.mat_albedo[m]; s_emission[m] = sc.mat_emission[m]; }
 	__syncthreads();            // the table is read by every wave in phase 2; k_shade<FIRST> reaches no other barrier before that (the early return above is block-uniform)
 
+	// this lane's ray of the stream for the block-iteration at hand, and its hit record: requested one iteration ahead, so that the
+	// first of the iteration's three dependent memory round trips is already under way
+	uint32_t next_slot = (blockIdx.x * kShadeBlock + threadIdx.x < n) ? queue_slot(qin, blockIdx.x * kShadeBlock, blockIdx.x * kShadeBlock + threadIdx.x) : 0u;
+	int32_t next_prim = prim_in[next_slot];
 	for (uint32_t base = blockIdx.x * kShadeBlock; base < n; base += gridDim.x * kShadeBlock, parity ^= 1u) {
 		// ---- phase 1, one lane per ray of the stream: misses end here; hits are only listed ----
 		bool is_hit = false;
-		const uint32_t my_slot = (base + threadIdx.x < n) ? queue_slot(qin, base, base + threadIdx.x) : 0u;     // this lane's ray of the stream
+		const uint32_t my_slot = next_slot;
+		const int32_t my_prim = next_prim;
+		{
+			const uint32_t nb = base + gridDim.x * kShadeBlock;
+			next_slot = (nb + threadIdx.x < n) ? queue_slot(qin, nb, nb + threadIdx.x) : 0u;
+			next_prim = prim_in[next_slot];
+		}
 		{
 			if (base + threadIdx.x < n) {
 				const uint32_t i = my_slot;
-				const int32_t prim = prim_in[i];
+				const int32_t prim = my_prim;
 				if (prim < 0) {
 					// MISS SHADER, Renderer.hpp:408-420 (Q10: throughput.r scales all three channels)
 					f3 R{0.0f, 0.0f, 0.0f};
