@@ -362,11 +362,13 @@ struct Trav {
 // Stack entries beyond the LDS-resident ones.  Kept OUTSIDE Trav: a dynamically indexed member would pin the whole struct
 // in scratch memory (every step would then reload the ray through VMEM); alone, only this rarely-touched array lives there.
 struct TravSpill { uint32_t e[kStack - kLdsStackWide]; };
-// Rays whose cone half-width exceeds kAlphaFat per unit of ray parameter (|D|^2 - 1 > ~1e-4: a few per million, produced
+// Rays whose cone half-width exceeds kAlphaFat per unit of ray parameter (|D|^2 - 1 > ~1e-3: a few per million, produced
 // by the reference's ill-conditioned tangent frame) are not traversed: the inflated ray would touch most of the tree and one
 // lane would walk it serially (measured: 20-57 ms per launch on a 100k-sphere scene).  They go to a "fat ray" list and
 // k_trace_fat intersects them with every sphere, a whole workgroup per ray — literally the reference's brute-force loop.
-constexpr float kAlphaFat = 0.01f;
+// (|D|^2 - 1 over the rays of S(100000), CPU twin, per million: 38 in (1e-4, 3e-4], 16 in (3e-4, 1e-3], 6 above.  With the limit
+// at 0.01 the detour took the 60 per million and 1.6 % of the cfg4 step; at 0.03 it takes the 6.)
+constexpr float kAlphaFat = 0.03f;
 MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float dy, float dz, float tfar, float alpha_extra = 0.0f) {     // true = fat ray
 	t.px = px; t.py = py; t.pz = pz; t.dx = dx; t.dy = dy; t.dz = dz;
 	float alpha;

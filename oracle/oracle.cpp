@@ -796,7 +796,7 @@ static float g_cone_fuzz = 0x1p-19f;
 struct RaySlab { float ia[3], na[3], ib[3], nb[3], c[3]; };
 // Rays with alpha > kAlphaFat skip the tree: the product hands them to k_trace_fat, which runs the brute-force loops
 // over all prims (csrc/kernels.hpp trav_begin / k_trace_fat); counters then grow by the prim count, no boxes.
-static constexpr float kAlphaFat = 0.01f;
+static constexpr float kAlphaFat = 0.03f;
 static inline RaySlab make_slab(float px, float py, float pz, float dx, float dy, float dz, bool* fat) {
 	RaySlab s;
 	const float L2 = (dx * dx + dy * dy) + dz * dz;
