@@ -602,6 +602,10 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 		// (Measured and dropped: REQUESTING THE NEXT RECORD EARLY — as soon as a lane knows its next node, into two register quads
 		// live across the passes: 51 VGPR spills around the loop and k_trace 249 -> 276 ms per cfg4 step; the other seven waves of
 		// the SIMD already cover the load at the head of each pass.)
+		// (Measured and dropped: the same request as an LDS-DMA load — global_load_lds_dwordx4 into one 16-B LDS slot per lane when the
+		// lane ARRIVES at a leaf, read by the leaf pass after s_waitcnt vmcnt(0); no registers, but 16 KB less of staged records:
+		// k_trace 226 -> 242 ms per cfg4 step.  Halving the resident waves costs 1.43x (227 -> 325 ms), so the loop is neither purely
+		// latency-bound nor purely issue-bound.)
 		// (Measured and dropped: SPECULATION — a lane parks the leaf it meets in a register and walks on until the wave's next leaf pass,
 		// so that node passes keep ~0.68 instead of ~0.61 of their lanes and leaf passes fill up.  The box tests made against the stale
 		// tfar cost more than that gains: 46 instead of 41 VALU wave-instructions per ray, k_trace 267 instead of 248 ms per cfg4 step.)
