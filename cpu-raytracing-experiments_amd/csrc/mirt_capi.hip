@@ -108,7 +108,9 @@ struct mirt_ctx {
 	uint64_t batch_seq = 0;
 
 	uint32_t deferred = 0;            // Accumulate() calls accepted by mirt_accumulate_async but not launched yet (fewer than a batch)
-	// launch-shape knobs for measurements (profiles/experiments/*): MIRT_TUNE_TRACE_WGS / MIRT_TUNE_SHADE_WGS = workgroups per CU
+	// launch-shape knobs for measurements (profiles/gpu_cycle.sh A/B runs), read from the environment at mirt_create: MIRT_TUNE_TRACE_WGS /
+	// MIRT_TUNE_SHADE_WGS = workgroups per CU, MIRT_TUNE_CHUNK = rays per work reservation, MIRT_TUNE_LEAF_BATCH = lanes at a leaf that
+	// trigger a leaf pass, MIRT_TUNE_REFILL_IDLE = idle lanes that trigger a refill.  They never change results.
 	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle;
 	// profiling
 	std::vector<TimedLaunch> pending;
