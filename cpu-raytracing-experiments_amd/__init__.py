@@ -321,7 +321,10 @@ class Renderer:
         out = (C.c_uint32 * 8)()
         self._check(self._lib.mirt_debug_info(self._ctx, out))
         keys = ("records", "lds_records", "lds_spheres", "depth", "half_boxes", "trace_lds_bytes", "trace_workgroups_per_cu", "cus")
-        return dict(zip(keys, [int(v) for v in out]))
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["wide"] = (d["half_boxes"] >> 1) & 1             # 64-B binary16 records of up to four children
+        d["half_boxes"] &= 1
+        return d
 
     def debug_primary_lists(self) -> list:
         """hist[n] = pixels whose candidate list holds n spheres (0..8), hist[9] = pixels without a list."""

@@ -50,6 +50,7 @@ struct SceneDev {
 	uint32_t lds_recs;          // records [0, lds_recs) are staged in LDS by the trace kernels (top of the tree)
 	uint32_t lds_spheres;       // spheres [0, lds_spheres) likewise (all of them, or none)
 	uint32_t half_boxes;        // 1: recs are the 32-B binary16 records (2 float4 each)
+	uint32_t wide;              // 1 (with half_boxes): recs are 64-B binary16 records of up to FOUR children (bvh_layout.hpp build_wide_half_records)
 	uint32_t chunk_max;         // rays per reservation from a launch's work counter, upper limit (pick_chunk)
 	uint32_t leaf_batch;        // lanes of a wave that must stand at a leaf before it runs a leaf pass (trace_persistent)
 	uint32_t refill_idle;       // idle lanes of a wave that trigger a refill (trace_persistent)
@@ -492,6 +493,55 @@ MIRT_DI void node_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpil
 	t.sp = sp;
 	t.cur = next;
 }
+// The node pass over 4-wide binary16 records (bvh_layout.hpp build_wide_half_records): one 64-B fetch, four slab tests, the nearest
+// hit child next (the lowest slot on ties), the other hit children pushed in slot order — sorting them by distance as well buys 2 %
+// fewer visits on S(100000) for three times the selection code (oracle twin, orc_wide_stats 1 vs 2).  Unused slots never hit.
+template <int MODE, bool COUNT, bool ALL_LDS, bool ST16>
+MIRT_DI void node_step_wide(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, uint32_t& n_nodes) {
+	const uint32_t cur = t.cur;
+	v4f q0, q1, q2, q3;
+	if (ALL_LDS || cur < sc.lds_recs) { const lds_v4f* r = lds.recs + cur; const uint32_t ns = sc.lds_recs; q0 = r[0]; q1 = r[ns]; q2 = r[2u * ns]; q3 = r[3u * ns]; }
+	else { const v4f* r = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(sc.recs) + (cur << 6)); q0 = r[0]; q1 = r[1]; q2 = r[2]; q3 = r[3]; }
+	const uint32_t x0 = __float_as_uint(q0.x), x1 = __float_as_uint(q0.y), x2 = __float_as_uint(q0.z), x3 = __float_as_uint(q0.w);
+	const uint32_t y0 = __float_as_uint(q1.x), y1 = __float_as_uint(q1.y), y2 = __float_as_uint(q1.z), y3 = __float_as_uint(q1.w);
+	const uint32_t z0 = __float_as_uint(q2.x), z1 = __float_as_uint(q2.y), z2 = __float_as_uint(q2.z), z3 = __float_as_uint(q2.w);
+	const uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y), r2 = __float_as_uint(q3.z), r3 = __float_as_uint(q3.w);
+	if (COUNT) {                                                              // boxes tested = the slots in use (an unused slot's lo.x is +inf)
+		n_nodes += ((x0 & 0x7fffu) != 0x7c00u) + (((x0 >> 16) & 0x7fffu) != 0x7c00u) + ((x1 & 0x7fffu) != 0x7c00u) + (((x1 >> 16) & 0x7fffu) != 0x7c00u);
+	}
+	const RaySlab& rs = t.rs;
+	float ta, tb, tc, td;
+	const bool ha = slab_hit(rs, __builtin_fmaf(half_lo(x0), rs.iax, rs.nax), __builtin_fmaf(half_lo(x2), rs.ibx, rs.nbx),
+	                         __builtin_fmaf(half_lo(y0), rs.iay, rs.nay), __builtin_fmaf(half_lo(y2), rs.iby, rs.nby),
+	                         __builtin_fmaf(half_lo(z0), rs.iaz, rs.naz), __builtin_fmaf(half_lo(z2), rs.ibz, rs.nbz), t.tfar, ta);
+	const bool hb = slab_hit(rs, __builtin_fmaf(half_hi(x0), rs.iax, rs.nax), __builtin_fmaf(half_hi(x2), rs.ibx, rs.nbx),
+	                         __builtin_fmaf(half_hi(y0), rs.iay, rs.nay), __builtin_fmaf(half_hi(y2), rs.iby, rs.nby),
+	                         __builtin_fmaf(half_hi(z0), rs.iaz, rs.naz), __builtin_fmaf(half_hi(z2), rs.ibz, rs.nbz), t.tfar, tb);
+	const bool hc = slab_hit(rs, __builtin_fmaf(half_lo(x1), rs.iax, rs.nax), __builtin_fmaf(half_lo(x3), rs.ibx, rs.nbx),
+	                         __builtin_fmaf(half_lo(y1), rs.iay, rs.nay), __builtin_fmaf(half_lo(y3), rs.iby, rs.nby),
+	                         __builtin_fmaf(half_lo(z1), rs.iaz, rs.naz), __builtin_fmaf(half_lo(z3), rs.ibz, rs.nbz), t.tfar, tc);
+	const bool hd = slab_hit(rs, __builtin_fmaf(half_hi(x1), rs.iax, rs.nax), __builtin_fmaf(half_hi(x3), rs.ibx, rs.nbx),
+	                         __builtin_fmaf(half_hi(y1), rs.iay, rs.nay), __builtin_fmaf(half_hi(y3), rs.iby, rs.nby),
+	                         __builtin_fmaf(half_hi(z1), rs.iaz, rs.naz), __builtin_fmaf(half_hi(z3), rs.ibz, rs.nbz), t.tfar, td);
+	// ---- the nearest hit child (lowest slot on ties) is next; the other hit children are pushed in slot order ----
+	const float inf = __builtin_inff();
+	ta = ha ? ta : inf; tb = hb ? tb : inf; tc = hc ? tc : inf; td = hd ? td : inf;
+	const bool b_ab = tb < ta, d_cd = td < tc;                                // within each pair the later slot wins only when strictly nearer
+	const float tab = b_ab ? tb : ta, tcd = d_cd ? td : tc;
+	const uint32_t rab = b_ab ? r1 : r0, rcd = d_cd ? r3 : r2;
+	const bool cd = tcd < tab;
+	const uint32_t near = cd ? rcd : rab;
+	const bool any = ha || hb || hc || hd;
+	uint32_t sp = t.sp;
+	if (ha && (cd || b_ab)) { stack_put<true, ST16>(lds, spill, sp, r0); sp += 1u; }
+	if (hb && (cd || !b_ab)) { stack_put<true, ST16>(lds, spill, sp, r1); sp += 1u; }
+	if (hc && (!cd || d_cd)) { stack_put<true, ST16>(lds, spill, sp, r2); sp += 1u; }
+	if (hd && (!cd || !d_cd)) { stack_put<true, ST16>(lds, spill, sp, r3); sp += 1u; }
+	uint32_t next = any ? near : kHalt;                                       // nothing hit and nothing stacked: finished
+	if (!any & (sp != 0u)) { --sp; next = stack_get<true, ST16>(lds, spill, sp); }
+	t.sp = sp;
+	t.cur = next;
+}
 template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16>
 MIRT_DI void leaf_step(const SceneDev& sc, const TraceLds lds, Trav& t, TravSpill& spill, bool& occluded, uint32_t& n_spheres, uint32_t pix, const Collect& col) {
 	const uint32_t first = t.cur & ~kLeafBit;
@@ -564,7 +614,7 @@ MIRT_DI uint32_t wave_take(bool want, WaveWindow& w, const Queue& q, uint32_t n,
 //     ray indices of the window and loads + sets up their rays — all as batched, mostly coalesced accesses.  (An earlier
 //     version also kept one prefetched ray per lane in registers; with the cone slab constants that pushed the kernel past
 //     64 VGPRs, i.e. from two 16-wave workgroups per CU to one, which cost far more than the prefetch saved.)
-template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, class LoadRay, class StoreResult>
+template <int MODE, bool COUNT, bool ALL_LDS, bool HALF, bool ST16, bool WIDE, class LoadRay, class StoreResult>
 MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue& q, uint32_t n, uint32_t* work_next, FatList fat, uint32_t& c_nodes, uint32_t& c_spheres,
                               LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
 	WaveWindow w{ 0, 0, 0, 0, pick_chunk(n, sc.chunk_max), true };
@@ -618,7 +668,7 @@ MIRT_DI void trace_persistent(const SceneDev& sc, const TraceLds tl, const Queue
 			if (node_m == 0ull || static_cast<uint32_t>(__popcll(leaf_m)) >= sc.leaf_batch) {
 				if (at_leaf) leaf_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, occluded, c_spheres, ri, col);
 			} else {
-				if (at_node) node_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, c_nodes);
+				if (at_node) { if (WIDE) node_step_wide<MODE, COUNT, ALL_LDS, ST16>(sc, tl, t, spill, c_nodes); else node_step<MODE, COUNT, ALL_LDS, HALF, ST16>(sc, tl, t, spill, c_nodes); }
 			}
 		}
 	}
@@ -654,9 +704,9 @@ MIRT_DI TraceLds stage_bvh(const SceneDev& sc, float4* lds_generic) {
 	lds_v4f* lds = (lds_v4f*)lds_generic;
 	const v4f* recs = reinterpret_cast<const v4f*>(sc.recs);
 	const v4f* sph = reinterpret_cast<const v4f*>(sc.spheres);
-	const uint32_t planes = sc.half_boxes ? 2u : 4u;                 // float4 per record
+	const uint32_t planes = (sc.half_boxes && !sc.wide) ? 2u : 4u;   // float4 per record
 	const uint32_t nq = sc.lds_recs * planes;
-	if (sc.half_boxes) { for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 1u) * sc.lds_recs + (j >> 1)] = recs[j]; }
+	if (planes == 2u) { for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 1u) * sc.lds_recs + (j >> 1)] = recs[j]; }
 	else { for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) lds[(j & 3u) * sc.lds_recs + (j >> 2)] = recs[j]; }   // AoS in HBM -> plane-major in LDS
 	for (uint32_t j = threadIdx.x; j < sc.lds_spheres; j += blockDim.x) lds[nq + j] = sph[j];
 	__syncthreads();
@@ -740,13 +790,17 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, 
                          LoadRay load_ray, StoreResult store_result, const Collect col = Collect{ nullptr, 0.0f, 0u }) {
 	if (n == 0) return;
 	const bool all = bvh_all_in_lds(sc);
-	if (sc.half_boxes) {
-		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 32768 records or spheres: never all in LDS
-		else if (all) trace_persistent<MODE, COUNT, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
-		else trace_persistent<MODE, COUNT, false, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+	if (sc.half_boxes && sc.wide) {
+		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 32768 records or spheres: never all in LDS
+		else if (all) trace_persistent<MODE, COUNT, true, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else trace_persistent<MODE, COUNT, false, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+	} else if (sc.half_boxes) {                                              // binary 32-B records: GPU-built trees, trees too deep for the wide layout
+		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else if (all) trace_persistent<MODE, COUNT, true, true, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else trace_persistent<MODE, COUNT, false, true, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 	} else {
-		if (all) trace_persistent<MODE, COUNT, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
-		else trace_persistent<MODE, COUNT, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		if (all) trace_persistent<MODE, COUNT, true, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
+		else trace_persistent<MODE, COUNT, false, false, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 	}
 }
 

@@ -111,7 +111,7 @@ struct mirt_ctx {
 	// launch-shape knobs for measurements (profiles/gpu_cycle.sh A/B runs), read from the environment at mirt_create: MIRT_TUNE_TRACE_WGS /
 	// MIRT_TUNE_SHADE_WGS = workgroups per CU, MIRT_TUNE_CHUNK = rays per work reservation, MIRT_TUNE_LEAF_BATCH = lanes at a leaf that
 	// trigger a leaf pass, MIRT_TUNE_REFILL_IDLE = idle lanes that trigger a refill.  They never change results.
-	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle;
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle, tune_wide = 1;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -503,6 +503,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	c->device = device;
 	if (const char* e = std::getenv("MIRT_TUNE_CHUNK")) c->tune_chunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 65536)) & ~63u;
 	if (const char* e = std::getenv("MIRT_TUNE_REFILL_IDLE")) c->tune_refill_idle = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
+	if (const char* e = std::getenv("MIRT_TUNE_WIDE")) c->tune_wide = std::atoi(e) != 0 ? 1u : 0u;
 	if (const char* e = std::getenv("MIRT_TUNE_LEAF_BATCH")) c->tune_leaf_batch = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
 	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
 	if (const char* e = std::getenv("MIRT_TUNE_SHADE_WGS")) c->tune_shade_wgs = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 16));
@@ -599,9 +600,9 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	}
 	std::memcpy(sky.data(), hdri_rgba, sky.size() * sizeof(float4));
 	std::vector<float> recs;
-	std::vector<uint32_t> half_recs;
+	std::vector<uint32_t> half_recs, wide_recs;
 	uint32_t depth = 0, n_recs = 0;
-	bool half = false;
+	bool half = false, wide = false;
 	int r;
 	if ((r = upload(c, c->spheres, sph))) return r;
 	const bool gpu_tree = c->policy.gpu_build && !c->policy.reference_tree && n_spheres >= 2;
@@ -635,7 +636,11 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 		if (!why.empty()) return fail(c, MIRT_ERR_ARG, "%s BVH rejected: %s", caller_tree ? "caller's" : "internal", why.c_str());
 		n_recs = static_cast<uint32_t>(recs.size() / 16);
 		half = c->allow_half && mirt_host::build_half_records(recs, half_recs);
-		if ((r = half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs))) return r;
+		// 4-wide binary16 records when the tree allows (bvh_layout.hpp build_wide_half_records): half as many dependent fetches per ray
+		uint32_t wide_levels = 0;
+		wide = half && c->tune_wide && mirt_host::build_wide_half_records(recs, wide_recs, &wide_levels);
+		if (wide) n_recs = static_cast<uint32_t>(wide_recs.size() / 16);
+		if ((r = wide ? upload(c, c->recs, wide_recs) : half ? upload(c, c->recs, half_recs) : upload(c, c->recs, recs))) return r;
 	}
 	if ((r = upload(c, c->prim_mat, pm)) ||
 	    (r = upload(c, c->light_sphere, lsp)) || (r = upload(c, c->light_emit, lem)) || (r = upload(c, c->mat_albedo, alb)) ||
@@ -652,8 +657,9 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	// LDS staging plan: the whole tree and every sphere packet when they fit the budget (1k spheres: 64 + 16 KB),
 	// otherwise the top of the tree only (records are breadth-first) and spheres from L2.
 	s.half_boxes = half ? 1u : 0u;
+	s.wide = wide ? 1u : 0u;
 	s.stack16 = (half && n_recs <= 32768 && n_spheres <= 32768) ? 1u : 0u;     // a stack entry = 15-bit record or prim index + the leaf flag
-	const uint32_t rec_bytes = half ? 32u : 64u, budget = stage_budget(half, s.stack16 != 0);
+	const uint32_t rec_bytes = (half && !wide) ? 32u : 64u, budget = stage_budget(half, s.stack16 != 0);
 	if (static_cast<uint64_t>(n_recs) * rec_bytes + static_cast<uint64_t>(n_spheres) * 16u <= budget) { s.lds_recs = n_recs; s.lds_spheres = n_spheres; }
 	else { s.lds_recs = std::min<uint32_t>(n_recs, budget / rec_bytes); s.lds_spheres = 0; }
 	c->trace_lds_bytes = s.lds_recs * rec_bytes + s.lds_spheres * 16u;
@@ -1015,7 +1021,7 @@ int mirt_debug_info(mirt_ctx* c, uint32_t out[8]) {
 	const SceneDev& s = c->scene;
 	uint32_t per_cu = kLdsPerCu / std::max<uint32_t>(trace_lds(c), 1u);
 	per_cu = std::min<uint32_t>(std::max<uint32_t>(per_cu, 1u), c->tune_trace_wgs);
-	out[0] = s.n_recs; out[1] = s.lds_recs; out[2] = s.lds_spheres; out[3] = c->bvh_depth; out[4] = s.half_boxes;
+	out[0] = s.n_recs; out[1] = s.lds_recs; out[2] = s.lds_spheres; out[3] = c->bvh_depth; out[4] = s.half_boxes | (s.wide << 1);
 	out[5] = trace_lds(c); out[6] = per_cu; out[7] = static_cast<uint32_t>(c->n_cu);
 	return MIRT_OK;
 }

@@ -256,8 +256,9 @@ int mirt_debug_trace_shadow(mirt_ctx* ctx, size_t n, const float* p_xyz, const f
  */
 int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out);
 /* Introspection of the GPU-internal BVH layout (tests, bench, DESIGN.md numbers):
- * out[0] records, out[1] records staged in LDS, out[2] spheres staged in LDS, out[3] tree depth, out[4] 1 if the 32-B
- * binary16 records are in use, out[5] dynamic LDS bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
+ * out[0] records, out[1] records staged in LDS, out[2] spheres staged in LDS, out[3] tree depth, out[4] bit 0: binary16
+ * records are in use, bit 1: they are the 64-B records of up to four children (else 32-B child pairs), out[5] dynamic LDS
+ * bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
 int mirt_debug_info(mirt_ctx* ctx, uint32_t out[8]);
 /* Length histogram of the per-pixel candidate lists of the current scene / camera / size (policy.trace_primary_rays = 0 path):
  * hist[n] = local pixels whose bundle of camera rays can hit n spheres (n = 0..8), hist[9] = pixels without a list (traced normally). */

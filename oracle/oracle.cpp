@@ -404,6 +404,7 @@ struct BVH {
 	std::vector<Box> padded;      // mode 2 only: conservative box per node (same indexing as nodes)
 	std::vector<uint32_t> slot_prim;   // mode 2 tree only: leaf slot -> index into the reference tree's prims (empty = identity)
 	float pad_rel = 0.0f;
+	bool wide = false;                 // mode 2 only: walk the tree as the product's 4-wide records do (csrc/bvh_layout.hpp build_wide_half_records)
 };
 
 static void bvh_build(const std::vector<Sphere>& primitives, BVH& out, std::vector<uint32_t>* order_out = nullptr) {
@@ -858,7 +859,7 @@ static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims
 		}
 	};
 	if (bvh.nodes[0].prim_count != 0) {            // single-leaf tree: the GPU record holds the leaf's box as child 0
-		float t0; lc.nodes += 2;
+		float t0; lc.nodes += bvh.wide ? 1 : 2;    // (the wide layout counts the slots in use, the binary one both children)
 		if (slab_test(rs, bvh.padded[0], *tfar, &t0)) leaf(bvh.nodes[0]);
 		return;
 	}
@@ -866,7 +867,24 @@ static inline void traverse_ray(const BVH& bvh, const std::vector<Sphere>& prims
 	uint32_t id = 0;
 	for (;;) {
 		if (bvh.nodes[id].prim_count != 0) leaf(bvh.nodes[id]);
-		else {
+		else if (bvh.wide) {
+			// node_step_wide() of csrc/kernels.hpp: the node stands for itself and its inner children — up to four kids, in the order
+			// [children of c0 ..., children of c1 ...]; all are tested against the current tfar, the nearest hit one (lowest slot on ties)
+			// is visited next, the other hit ones are pushed in slot order
+			uint32_t kids[4]; int nk = 0;
+			for (uint32_t c = bvh.nodes[id].first_id; c <= bvh.nodes[id].first_id + 1; c++) {
+				if (bvh.nodes[c].prim_count == 0) { kids[nk++] = bvh.nodes[c].first_id; kids[nk++] = bvh.nodes[c].first_id + 1; }
+				else kids[nk++] = c;
+			}
+			lc.nodes += static_cast<uint64_t>(nk);
+			float t[4]; bool h[4]; int m = -1;
+			for (int k = 0; k < nk; k++) { h[k] = slab_test(rs, bvh.padded[kids[k]], *tfar, &t[k]); if (h[k] && (m < 0 || t[k] < t[m])) m = k; }
+			if (m >= 0) {
+				for (int k = 0; k < nk; k++) if (h[k] && k != m) { if (sp >= 64) abort(); stack[sp++] = kids[k]; }
+				id = kids[m];
+				continue;
+			}
+		} else {
 			const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
 			float ta, tb;
 			lc.nodes += 2;
@@ -904,7 +922,7 @@ static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>
 		return false;
 	};
 	if (bvh.nodes[0].prim_count != 0) {
-		float t0; lc.shadow_nodes += 2;
+		float t0; lc.shadow_nodes += bvh.wide ? 1 : 2;
 		return slab_test(rs, bvh.padded[0], tfar, &t0) && leaf(bvh.nodes[0]);
 	}
 	uint32_t stack[64]; size_t sp = 0;
@@ -915,7 +933,21 @@ static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>
 		// S(10000) 51.5 vs 54.5, S(100000) 61.1 vs 68.0 (the NEE rays of these scenes cross the sphere field towards one of a few
 		// lights and ~80 % are occluded somewhere along the way: the order matters more the deeper the tree).
 		if (bvh.nodes[id].prim_count != 0) { if (leaf(bvh.nodes[id])) return true; }
-		else {
+		else if (bvh.wide) {
+			uint32_t kids[4]; int nk = 0;
+			for (uint32_t c = bvh.nodes[id].first_id; c <= bvh.nodes[id].first_id + 1; c++) {
+				if (bvh.nodes[c].prim_count == 0) { kids[nk++] = bvh.nodes[c].first_id; kids[nk++] = bvh.nodes[c].first_id + 1; }
+				else kids[nk++] = c;
+			}
+			lc.shadow_nodes += static_cast<uint64_t>(nk);
+			float t[4]; bool h[4]; int m = -1;
+			for (int k = 0; k < nk; k++) { h[k] = slab_test(rs, bvh.padded[kids[k]], tfar, &t[k]); if (h[k] && (m < 0 || t[k] < t[m])) m = k; }
+			if (m >= 0) {
+				for (int k = 0; k < nk; k++) if (h[k] && k != m) { if (sp >= 64) abort(); stack[sp++] = kids[k]; }
+				id = kids[m];
+				continue;
+			}
+		} else {
 			const uint32_t c0 = bvh.nodes[id].first_id, c1 = c0 + 1;
 			float ta, tb;
 			lc.shadow_nodes += 2;
@@ -930,6 +962,47 @@ static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>
 	}
 }
 
+// diagnostic (orc_wide_stats): what the same walk would cost on the tree collapsed to 4-wide nodes — every inner node
+// absorbs its inner children, the hit children of a wide node are visited nearest first, leaves are stack items as above.  Counts
+// wide-node visits (= dependent record fetches per ray) and box tests; results are discarded.
+static std::atomic<uint64_t> g_wide[6];           // closest: rays, visits, boxes; shadow: rays, visits, boxes
+static bool g_wide_on = false;
+static int g_wide_variant = 0;
+static void wide_walk(const BVH& bvh, const std::vector<Sphere>& prims, float px, float py, float pz, float dx, float dy, float dz, float tfar_in, bool anyhit) {
+	bool fat;
+	const RaySlab rs = make_slab(px, py, pz, dx, dy, dz, &fat);
+	if (fat || bvh.nodes.empty() || bvh.nodes[0].prim_count != 0) return;
+	float tfar = tfar_in; int32_t primID = -1;
+	uint64_t visits = 0, boxes = 0;
+	uint32_t stack[256]; size_t sp = 0;
+	uint32_t id = 0;
+	for (;;) {
+		const Node& n = bvh.nodes[id];
+		if (n.prim_count != 0) {
+			const uint32_t p = bvh.slot_prim.empty() ? n.first_id : bvh.slot_prim[n.first_id];
+			if (anyhit) { if (sphere_occludes(prims[p], px, py, pz, dx, dy, dz, tfar)) break; }
+			else sphere_closest_tie(prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, &tfar, &primID);
+		} else {
+			uint32_t kids[4]; int nk = 0;
+			for (uint32_t c = n.first_id; c <= n.first_id + 1; c++) {
+				if (bvh.nodes[c].prim_count == 0) { kids[nk++] = bvh.nodes[c].first_id; kids[nk++] = bvh.nodes[c].first_id + 1; }
+				else kids[nk++] = c;
+			}
+			visits++; boxes += static_cast<uint64_t>(nk);
+			float t[4]; uint32_t hit[4]; int nh = 0;
+			for (int k = 0; k < nk; k++) { float tn; if (slab_test(rs, bvh.padded[kids[k]], tfar, &tn)) { t[nh] = tn; hit[nh] = kids[k]; nh++; } }
+			if (g_wide_variant == 0) { for (int a = 1; a < nh; a++) for (int b = a; b > 0 && t[b] < t[b - 1]; b--) { std::swap(t[b], t[b - 1]); std::swap(hit[b], hit[b - 1]); } }
+			else { int m = 0; for (int a = 1; a < nh; a++) if (t[a] < t[m]) m = a; if (nh) { std::swap(t[0], t[m]); std::swap(hit[0], hit[m]); } }     // nearest first, the rest as stored
+			for (int k = nh - 1; k >= 1; k--) if (sp < 256) stack[sp++] = hit[k];
+			if (nh) { id = hit[0]; continue; }
+		}
+		if (sp == 0) break;
+		id = stack[--sp];
+	}
+	const int o = anyhit ? 3 : 0;
+	g_wide[o]++; g_wide[o + 1] += visits; g_wide[o + 2] += boxes;
+}
+
 // ---------------------------------------------------------------------------------
 // Oracle context
 // ---------------------------------------------------------------------------------
@@ -941,7 +1014,7 @@ struct Oracle {
 	Sky sky;
 	BVH bvh;                              // the reference's tree (BVH.hpp:90-206): modes 0 and 1, and the prim order of every mode
 	BVH accel;                            // mode 2: the tree the HIP kernels traverse (internal SAH tree, or a copy of `bvh`)
-	bool accel_internal = true, accel_half = false;
+	bool accel_internal = true, accel_half = false, accel_wide = false;
 	uint32_t width = 0, height = 0, h_tiles = 0, v_tiles = 0;
 	uint32_t accumulations = 0;
 	uint32_t max_bounces = 16;            // Renderer.hpp:24
@@ -971,8 +1044,10 @@ static void traverse(const Oracle& o, const Buffer& in, Hit& out, size_t size, L
 		if (!o.bvh.nodes.empty()) traverse_stream(o.bvh, in, out, size, lc);
 	} else {
 		if (!o.accel.nodes.empty())
-			for (size_t i = 0; i < size; i++)
+			for (size_t i = 0; i < size; i++) {
+				if (g_wide_on) wide_walk(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], out.tfar[i], false);
 				traverse_ray(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], &out.tfar[i], &out.primID[i], lc);
+			}
 	}
 	for (size_t i = 0; i < size; i++)                                                                          // :313-317 / :350-354
 		if (int32_t primID = out.primID[i]; primID >= 0) out.matID[i] = o.bvh.prims[primID].material_ID;
@@ -985,9 +1060,11 @@ static void traverse_shadow(const Oracle& o, ShadowStream& in, size_t size, Loca
 		if (!o.bvh.nodes.empty()) traverse_stream_shadow(o.bvh, in, size, lc);
 	} else {
 		if (!o.accel.nodes.empty())
-			for (size_t i = 0; i < size; i++)
+			for (size_t i = 0; i < size; i++) {
+				if (g_wide_on) wide_walk(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], in.tfar[i], true);
 				if (traverse_ray_shadow(o.accel, o.bvh.prims, in.p.x[i], in.p.y[i], in.p.z[i], in.dir.x[i], in.dir.y[i], in.dir.z[i], in.tfar[i], lc))
 					in.occluded.set(i);
+			}
 	}
 }
 
@@ -1292,6 +1369,7 @@ static void build_accel(Oracle& o) {
 	}
 	bvh_pad(o.accel, o.bvh.prims, 0x1p-18f);
 	if (o.accel_half) bvh_quantize_half(o.accel);
+	o.accel.wide = o.accel_wide;
 }
 
 extern "C" {
@@ -1319,11 +1397,12 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	}
 	return 0;
 }
+void orc_wide_stats(int on, uint64_t* out) { g_wide_on = on != 0; g_wide_variant = on > 1 ? 1 : 0; if (out) for (int i = 0; i < 6; i++) out[i] = g_wide[i]; }
 void orc_len_hist(int on, uint64_t* out) { g_len_hist_on = on != 0; if (out) for (int i = 0; i < 16; i++) out[i] = g_len_hist[i]; }
 void orc_set_cone_fuzz(float f) { g_cone_fuzz = f; }
 void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.accel, o.bvh.prims, pad_rel); if (o.accel_half) bvh_quantize_half(o.accel); }
 // internal_tree: 1 = internal SAH tree (product default), 0 = the reference tree; half: binary16 boxes (product's 32-B records)
-void orc_set_mode2_tree(void* h, int internal_tree, int half) { Oracle& o = *static_cast<Oracle*>(h); o.accel_internal = internal_tree != 0; o.accel_half = half != 0; build_accel(o); }
+void orc_set_mode2_tree(void* h, int internal_tree, int half, int wide) { Oracle& o = *static_cast<Oracle*>(h); o.accel_internal = internal_tree != 0; o.accel_half = half != 0; o.accel_wide = wide != 0; build_accel(o); }
 int orc_node_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->bvh.nodes.size()); }
 int orc_light_count(void* h) { return static_cast<int>(static_cast<Oracle*>(h)->lights.size()); }
 void orc_get_bvh(void* h, void* nodes, void* prims) {

@@ -40,7 +40,7 @@ def load():
     lib.orc_create.restype = vp
     lib.orc_destroy.argtypes = [vp]
     lib.orc_set_scene.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32]
-    lib.orc_set_mode2_tree.argtypes = [vp, i32, i32]
+    lib.orc_set_mode2_tree.argtypes = [vp, i32, i32, i32]
     lib.orc_node_count.argtypes = [vp]
     lib.orc_light_count.argtypes = [vp]
     lib.orc_get_bvh.argtypes = [vp, vp, vp]
@@ -127,14 +127,16 @@ class Oracle:
         ori = np.ascontiguousarray(cam.orient, dtype=np.float32)
         self.lib.orc_set_camera(self.h, _p(pos), _p(ori), float(cam.half_width), float(cam.half_height), float(cam.z), float(cam.exposure))
 
-    def set_mode2_tree(self, internal_tree=True, half=False):
-        """Mode 2 only: which tree the twin traverses (internal SAH tree like the product's default, or the reference tree)
-        and whether its boxes are rounded outward to binary16 like the product's 32-B records.  Call after update_scene."""
-        self.lib.orc_set_mode2_tree(self.h, int(bool(internal_tree)), int(bool(half)))
+    def set_mode2_tree(self, internal_tree=True, half=False, wide=False):
+        """Mode 2 only: which tree the twin traverses (internal SAH tree like the product's default, or the reference tree),
+        whether its boxes are rounded outward to binary16 like the product's half-precision records, and whether it is walked
+        four children at a time like the product's 64-B wide records.  Call after update_scene."""
+        self.lib.orc_set_mode2_tree(self.h, int(bool(internal_tree)), int(bool(half)), int(bool(wide)))
 
     def match_product(self, renderer):
         """Configure the mode-2 twin exactly like a product Renderer's GPU-internal BVH."""
-        self.set_mode2_tree(not renderer.policy.reference_tree, renderer.debug_info()["half_boxes"])
+        info = renderer.debug_info()
+        self.set_mode2_tree(not renderer.policy.reference_tree, info["half_boxes"], info["wide"])
 
     def bvh(self):
         n = self.lib.orc_node_count(self.h)

@@ -246,7 +246,9 @@ def test_tree_and_record_variants_agree(mirt, allow_half, reference_tree):
     r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, allow_half_boxes=allow_half, reference_tree=reference_tree, count_traffic=True, trace_primary_rays=True)
     r.Resize(128, 128); r.Accumulate(5)
     info = r.debug_info()
-    assert info["half_boxes"] == int(allow_half) and info["records"] == 999 and info["lds_records"] == 999 and info["lds_spheres"] == 1000
+    assert info["half_boxes"] == int(allow_half) and info["wide"] == int(allow_half) and info["lds_records"] == info["records"]
+    assert info["lds_spheres"] == (1000 if info["records"] * (64 if info["wide"] or not allow_half else 32) + 16000 <= (48 if allow_half else 96) * 1024 else 0)    # records AND spheres staged when both fit
+    assert info["records"] == 999 if not allow_half else 333 <= info["records"] < 999       # binary16 records hold up to four children: a node and its inner children
     assert info["trace_workgroups_per_cu"] == (2 if allow_half else 1)
     assert_same(r.accumulator(), o.accumulator(), f"accumulator (half={allow_half}, reference_tree={reference_tree})")
     t = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(128, 128); t.Accumulate(5)
@@ -282,7 +284,7 @@ def test_deep_stack_and_wide_references(mirt):
             chain["first_id"][2 * k + 1] = order[k]; chain["prim_count"][2 * k + 1] = 1
         chain["first_id"][2 * n - 2] = order[n - 1]; chain["prim_count"][2 * n - 2] = 1
         r.UpdateScene(nodes=chain)
-        assert r.debug_info()["depth"] >= n
+        assert r.debug_info()["depth"] >= n and r.debug_info()["wide"] == 0          # too deep for the 4-wide records (three stack entries per level): child-pair records
         r.Resize(64, 48); r.Accumulate(5)
         assert_same(r.accumulator(), o.accumulator(), f"chain tree, stack {n - 1} deep (trace_primary_rays={primary})")
         c = r.counters()
@@ -291,7 +293,7 @@ def test_deep_stack_and_wide_references(mirt):
     big = mirt.scene.synthetic(40000)
     r = mirt.Renderer(big, max_bounces=4, use_bvh=True, count_traffic=True, trace_primary_rays=True); r.Resize(64, 48); r.Accumulate(5)
     info = r.debug_info()
-    assert info["half_boxes"] == 1 and info["records"] == 39999 and info["lds_records"] == 1024          # 32 KB of staged records: the u32-stack plan
+    assert info["half_boxes"] == 1 and info["wide"] == 1 and info["records"] < 39999 and info["lds_records"] == 512          # 32 KB of staged 64-B records: the u32-stack plan
     t = ob.Oracle(big, max_bounces=4, trav_mode=ob.TRAV_PER_RAY_BVH); t.match_product(r); t.Resize(64, 48); t.Accumulate(5)
     assert_same(r.accumulator(), t.accumulator(), "S(40000) vs the twin")
     cg, ct = r.counters(), t.counters()
@@ -311,7 +313,8 @@ def test_gpu_built_tree_gives_the_same_results(mirt, scene_name, allow_half, w, 
     g = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, allow_half_boxes=allow_half, count_traffic=True, gpu_build=True); g.Resize(w, h); g.Accumulate(spp)
     n = len(sc.geometry)
     ia, ig = a.debug_info(), g.debug_info()
-    assert ig["records"] == n - 1 == ia["records"] and ig["half_boxes"] == ia["half_boxes"] and ig["depth"] <= 64
+    assert ig["records"] == n - 1 and ig["wide"] == 0 and ig["half_boxes"] == ia["half_boxes"] and ig["depth"] <= 64    # the GPU-built tree keeps child-pair records
+    assert ia["records"] == n - 1 if not ia["wide"] else ia["records"] < n - 1
     assert_same(g.accumulator(), a.accumulator(), f"{scene_name}: GPU-built tree vs host SAH tree")
     ca, cg = a.counters(), g.counters()
     assert cg["rays"] == ca["rays"] and cg["shadow_rays"] == ca["shadow_rays"] and cg["terminated"] == ca["terminated"]
@@ -360,7 +363,7 @@ def test_caller_tree_with_multi_prim_leaves(mirt):
         r.Resize(96, 96); r.Accumulate(5)
         assert r.debug_info()["half_boxes"] == int(allow_half)
         assert_same(r.accumulator(), o.accumulator(), f"multi-prim leaves, half={allow_half}")
-        assert r.debug_info()["records"] == len(prims) - 1   # every k-prim leaf became a subtree of k one-prim leaves (bvh_layout.hpp)
+        assert r.debug_info()["records"] == len(prims) - 1 if not allow_half else r.debug_info()["records"] < len(prims) - 1   # every k-prim leaf became a subtree of k one-prim leaves (bvh_layout.hpp); binary16 records are 4-wide
         r.close()
 
 
@@ -679,7 +682,7 @@ def test_large_scenes_bvh_equals_brute_force(mirt, n, w, h, spp, mb):
     for reference_tree in (False, True):
         r = mirt.Renderer(sc, max_bounces=mb, use_bvh=True, reference_tree=reference_tree); r.Resize(w, h); r.Accumulate(spp)
         info = r.debug_info()
-        assert info["records"] == n - 1 and 0 < info["lds_records"] < info["records"] and info["lds_spheres"] == 0
+        assert info["wide"] == 1 and n // 3 <= info["records"] < n - 1 and 0 < info["lds_records"] < info["records"] and info["lds_spheres"] == 0
         assert_same(r.accumulator(), want, f"S({n}) BVH (reference_tree={reference_tree}) vs brute force")
         assert r.counters()["rays"] == wc["rays"] and r.counters()["terminated"] == wc["terminated"]
         r.close()

@@ -209,6 +209,13 @@ def test_robust_bvh_equals_brute_force(mirt):
         assert cr["rays"] == ct["rays"] and cr["terminated"] == ct["terminated"]
         assert 0 < ct["shadow_rays"] <= cr["shadow_rays"]   # the twin, like the product, emits no NEE rays for last-bounce hits (their paths are dropped, Q5)
         assert ct["spheres"] < cr["spheres"]
+        # the same tree walked four children at a time (the product's 64-B binary16 records): same answer, about half the node visits
+        wide = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); wide.set_mode2_tree(True, True, True); wide.Resize(w, h); wide.Accumulate(spp)
+        pair = ob.Oracle(sc, max_bounces=mb, trav_mode=ob.TRAV_PER_RAY_BVH); pair.set_mode2_tree(True, True, False); pair.Resize(w, h); pair.Accumulate(spp)
+        assert np.array_equal(bits(ref.accumulator()), bits(wide.accumulator())) and np.array_equal(bits(ref.accumulator()), bits(pair.accumulator()))
+        cw, cp = wide.counters(), pair.counters()
+        assert cw["rays"] == cr["rays"] and cw["shadow_rays"] == cp["shadow_rays"]
+        assert cw["nodes"] < 1.25 * cp["nodes"] and cw["shadow_nodes"] < 1.25 * cp["shadow_nodes"]      # box tests: about as many
 
 
 def test_reference_stream_bvh_differs_from_its_brute_force_only_rarely(mirt):
