@@ -533,10 +533,21 @@ MIRT_DI void node_step_wide(const SceneDev& sc, const TraceLds lds, Trav& t, Tra
 	const uint32_t near = cd ? rcd : rab;
 	const bool any = ha || hb || hc || hd;
 	uint32_t sp = t.sp;
-	if (ha && (cd || b_ab)) { stack_put<true, ST16>(lds, spill, sp, r0); sp += 1u; }
-	if (hb && (cd || !b_ab)) { stack_put<true, ST16>(lds, spill, sp, r1); sp += 1u; }
-	if (hc && (!cd || d_cd)) { stack_put<true, ST16>(lds, spill, sp, r2); sp += 1u; }
-	if (hd && (!cd || !d_cd)) { stack_put<true, ST16>(lds, spill, sp, r3); sp += 1u; }
+	constexpr uint32_t lds_entries = ST16 ? kLdsStack : kLdsStackWide;
+	if (__ballot(sp + 3u > lds_entries) == 0ull) {
+		// the usual case, decided for the wave: whatever a lane pushes stays within its LDS entries — four plain conditional writes
+		// instead of four times the LDS / scratch / overflow nest of stack_put
+		constexpr uint32_t lstride = kTraceBlock;
+		if (ha && (cd || b_ab)) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(r0 | (r0 >> 16)); else lds.stack[sp * lstride + threadIdx.x] = r0; sp += 1u; }
+		if (hb && (cd || !b_ab)) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(r1 | (r1 >> 16)); else lds.stack[sp * lstride + threadIdx.x] = r1; sp += 1u; }
+		if (hc && (!cd || d_cd)) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(r2 | (r2 >> 16)); else lds.stack[sp * lstride + threadIdx.x] = r2; sp += 1u; }
+		if (hd && (!cd || !d_cd)) { if (ST16) ((lds_u16*)lds.stack)[sp * lstride + threadIdx.x] = static_cast<uint16_t>(r3 | (r3 >> 16)); else lds.stack[sp * lstride + threadIdx.x] = r3; sp += 1u; }
+	} else {
+		if (ha && (cd || b_ab)) { stack_put<true, ST16>(lds, spill, sp, r0); sp += 1u; }
+		if (hb && (cd || !b_ab)) { stack_put<true, ST16>(lds, spill, sp, r1); sp += 1u; }
+		if (hc && (!cd || d_cd)) { stack_put<true, ST16>(lds, spill, sp, r2); sp += 1u; }
+		if (hd && (!cd || !d_cd)) { stack_put<true, ST16>(lds, spill, sp, r3); sp += 1u; }
+	}
 	uint32_t next = any ? near : kHalt;                                       // nothing hit and nothing stacked: finished
 	if (!any & (sp != 0u)) { --sp; next = stack_get<true, ST16>(lds, spill, sp); }
 	t.sp = sp;
