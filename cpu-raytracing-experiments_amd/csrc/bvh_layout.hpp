@@ -13,6 +13,10 @@
 // One 64-B fetch therefore serves both of a node's children (the reference stores them adjacently at
 // first_id, first_id+1 for the same reason).
 //
+// DEFAULT LAYOUT: 4-wide binary16 records (64 B: a node and its inner children, build_wide_half_records below) whenever binary16
+// is precise enough and the tree is not too deep; the child-pair records described here remain for GPU-built trees, deep trees
+// and f32 planes.
+//
 // Half-precision variant (32 B per record, used when it is precise enough for the scene): the same twelve planes as
 // IEEE binary16, lo planes rounded toward -inf and hi planes toward +inf so the boxes only ever grow:
 //     words 0..5 = (lo0|lo1<<16, hi0|hi1<<16) for x, y, z;  words 6,7 = child references.
