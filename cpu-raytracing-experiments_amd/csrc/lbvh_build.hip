@@ -216,6 +216,57 @@ __global__ __launch_bounds__(kBlock) void k_emit_records(const uint64_t* __restr
 	}
 }
 
+// 4-WIDE binary16 records (bvh_layout.hpp build_wide_half_records): a wide node is an inner node at an odd depth (root = 1) — it
+// absorbs its inner children.  wide_flag[r] = 1 for the wide nodes in breadth-first record order r; its exclusive sum numbers them.
+__global__ __launch_bounds__(kBlock) void k_wide_flags(uint32_t n_inner, const uint64_t* __restrict__ order_sorted, uint32_t* __restrict__ flag) {
+	const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+	if (r >= n_inner) return;
+	flag[r] = static_cast<uint32_t>(order_sorted[r] >> 32) & 1u;
+}
+__global__ __launch_bounds__(kBlock) void k_emit_wide(const uint64_t* __restrict__ keys, uint32_t n_inner, const uint64_t* __restrict__ order_sorted, const uint32_t* __restrict__ child0,
+                                                      const uint32_t* __restrict__ child1, const uint32_t* __restrict__ rec_of, const uint32_t* __restrict__ wide_index,
+                                                      const Box* __restrict__ leaf_box, const Box* __restrict__ inner_box, uint32_t* __restrict__ recs_wide, uint32_t* n_wide) {
+	const uint32_t r = blockIdx.x * kBlock + threadIdx.x;                   // breadth-first record number of a binary node
+	if (r >= n_inner) return;
+	const uint64_t key = order_sorted[r];
+	if (((key >> 32) & 1u) == 0u) return;                                   // even depth: absorbed by its parent
+	const uint32_t i = static_cast<uint32_t>(key);
+	atomicMax(n_wide, wide_index[r] + 1u);                                  // the count of wide records = the last index + 1
+	Box b[4]; uint32_t ref[4]; int nk = 0;
+	auto child_pair = [&](uint32_t node, uint32_t out[2]) {                // a node's children, the one with the larger half area first (as k_emit_records)
+		const uint32_t c[2] = { child0[node], child1[node] };
+		Box cb[2];
+		for (int k = 0; k < 2; k++) cb[k] = (c[k] & kLeafBit) ? leaf_box[static_cast<uint32_t>(keys[c[k] & ~kLeafBit])] : inner_box[c[k]];
+		const int first = (half_area(cb[0]) < half_area(cb[1])) ? 1 : 0;
+		out[0] = c[first]; out[1] = c[first ^ 1];
+	};
+	uint32_t c[2]; child_pair(i, c);
+	for (int k = 0; k < 2; k++) {
+		if (c[k] & kLeafBit) {
+			const uint32_t prim = static_cast<uint32_t>(keys[c[k] & ~kLeafBit]);
+			b[nk] = leaf_box[prim]; ref[nk] = kLeafBit | prim; nk++;
+		} else {
+			uint32_t g[2]; child_pair(c[k], g);
+			for (int j = 0; j < 2; j++) {
+				if (g[j] & kLeafBit) { const uint32_t prim = static_cast<uint32_t>(keys[g[j] & ~kLeafBit]); b[nk] = leaf_box[prim]; ref[nk] = kLeafBit | prim; }
+				else { b[nk] = inner_box[g[j]]; ref[nk] = wide_index[rec_of[g[j]]]; }      // an inner grandchild is two levels down: a wide node again
+				nk++;
+			}
+		}
+	}
+	uint32_t lo[3][4], hi[3][4];
+	for (int k = 0; k < 4; k++) {
+		for (int a = 0; a < 3; a++) { lo[a][k] = k < nk ? half_down(b[k].lo[a]) : 0x7c00u; hi[a][k] = k < nk ? half_up(b[k].hi[a]) : 0x7c00u; }   // unused slot: the +inf box no slab test hits
+		if (k >= nk) ref[k] = ref[0];
+	}
+	uint32_t* q = recs_wide + static_cast<size_t>(wide_index[r]) * 16;
+	for (int a = 0; a < 3; a++) {
+		q[a * 4 + 0] = lo[a][0] | (lo[a][1] << 16); q[a * 4 + 1] = lo[a][2] | (lo[a][3] << 16);
+		q[a * 4 + 2] = hi[a][0] | (hi[a][1] << 16); q[a * 4 + 3] = hi[a][2] | (hi[a][3] << 16);
+	}
+	for (int k = 0; k < 4; k++) q[12 + k] = ref[k];
+}
+
 struct Scratch {
 	void* p = nullptr;
 	hipError_t get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
@@ -227,7 +278,8 @@ struct Scratch {
 
 } // namespace
 
-bool build_lbvh(hipStream_t st, const float4* spheres, uint32_t n, float* recs32, uint32_t* recs16, uint32_t* depth_out, std::string* err) {
+bool build_lbvh(hipStream_t st, const float4* spheres, uint32_t n, float* recs32, uint32_t* recs16, uint32_t* depth_out, std::string* err,
+                uint32_t* recs_wide, uint32_t* n_wide_out) {
 	if (n < 2) { if (err) *err = "fewer than two spheres"; return false; }
 	const uint32_t n_inner = n - 1;
 	Scratch leaf_box, inner_box, keys, keys_sorted, order_keys, order_sorted, c0, c1, par_inner, par_leaf, small, sort_tmp;
@@ -263,10 +315,26 @@ bool build_lbvh(hipStream_t st, const float4* spheres, uint32_t n, float* recs32
 	hipLaunchKernelGGL(k_emit_records, gi, blk, 0, st, keys_sorted.as<uint64_t>(), n_inner, c0.as<uint32_t>(), c1.as<uint32_t>(), rec_of, leaf_box.as<Box>(), inner_box.as<Box>(),
 	                   recs32, recs16);
 	LBVH_TRY(hipGetLastError());
-	uint32_t depth = 0;
+	uint32_t depth = 0, n_wide = 0;
+	Scratch wide_flag, wide_index, scan_tmp;
+	if (recs_wide) {
+		// number the wide nodes (odd depth) in breadth-first order and emit one 64-B record each
+		LBVH_TRY(wide_flag.get(4ull * n_inner)); LBVH_TRY(wide_index.get(4ull * n_inner));
+		size_t scan_bytes = 0;
+		LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, wide_flag.as<uint32_t>(), wide_index.as<uint32_t>(), static_cast<int>(n_inner), st));
+		LBVH_TRY(scan_tmp.get(scan_bytes));
+		hipLaunchKernelGGL(k_wide_flags, gi, blk, 0, st, n_inner, order_sorted.as<uint64_t>(), wide_flag.as<uint32_t>());
+		LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, wide_flag.as<uint32_t>(), wide_index.as<uint32_t>(), static_cast<int>(n_inner), st));
+		uint32_t* n_wide_dev = centre_bounds + 7;                           // a spare word of `small` (zeroed above)
+		hipLaunchKernelGGL(k_emit_wide, gi, blk, 0, st, keys_sorted.as<uint64_t>(), n_inner, order_sorted.as<uint64_t>(), c0.as<uint32_t>(), c1.as<uint32_t>(), rec_of, wide_index.as<uint32_t>(),
+		                   leaf_box.as<Box>(), inner_box.as<Box>(), recs_wide, n_wide_dev);
+		LBVH_TRY(hipGetLastError());
+		LBVH_TRY(hipMemcpyAsync(&n_wide, n_wide_dev, 4, hipMemcpyDeviceToHost, st));
+	}
 	LBVH_TRY(hipMemcpyAsync(&depth, max_depth, 4, hipMemcpyDeviceToHost, st));
 	LBVH_TRY(hipStreamSynchronize(st));
 	if (depth_out) *depth_out = depth;
+	if (n_wide_out) *n_wide_out = n_wide;
 	return true;
 }
 

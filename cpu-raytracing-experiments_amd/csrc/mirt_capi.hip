@@ -86,7 +86,7 @@ struct mirt_ctx {
 	bool have_scene = false, have_camera = false;
 
 	// scene
-	DeviceBuffer recs, spheres, prim_mat, light_sphere, light_emit, mat_albedo, mat_emission, hdri;
+	DeviceBuffer recs, recs_wide, spheres, prim_mat, light_sphere, light_emit, mat_albedo, mat_emission, hdri;
 	SceneDev scene{};
 	CameraParams camera{};
 	uint32_t trace_lds_bytes = 0;    // dynamic LDS of the BVH trace kernels (staged records + spheres)
@@ -530,7 +530,7 @@ int mirt_destroy(mirt_ctx* c) {
 	}
 	c->slots.clear();
 	for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-	DeviceBuffer* bufs[] = { &c->recs, &c->spheres, &c->prim_mat, &c->light_sphere, &c->light_emit, &c->mat_albedo, &c->mat_emission,
+	DeviceBuffer* bufs[] = { &c->recs, &c->recs_wide, &c->spheres, &c->prim_mat, &c->light_sphere, &c->light_emit, &c->mat_albedo, &c->mat_emission,
 	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->counters };
 	for (DeviceBuffer* b : bufs) b->release();
 	if (c->frame_host) (void)hipHostFree(c->frame_host);
@@ -602,7 +602,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	std::vector<float> recs;
 	std::vector<uint32_t> half_recs, wide_recs;
 	uint32_t depth = 0, n_recs = 0;
-	bool half = false, wide = false;
+	bool half = false, wide = false, wide_gpu = false;
 	int r;
 	if ((r = upload(c, c->spheres, sph))) return r;
 	const bool gpu_tree = c->policy.gpu_build && !c->policy.reference_tree && n_spheres >= 2;
@@ -616,10 +616,15 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 			if (amax > 60000.0f || 2.0f * rad < 8.0f * mirt_host::half_ulp_at(amax)) half = false;
 		}
 		HIP_TRY(c, c->recs.ensure(static_cast<size_t>(n_recs) * (half ? 32u : 64u)));
+		const bool want_wide = half && c->tune_wide;                         // the 4-wide binary16 records as well (used when the tree is shallow enough)
+		if (want_wide) HIP_TRY(c, c->recs_wide.ensure(static_cast<size_t>(n_recs) * 64u));
 		std::string why;
-		if (!mirt_gpu::build_lbvh(c->stream, c->spheres.as<float4>(), n_spheres, half ? nullptr : c->recs.as<float>(), half ? c->recs.as<uint32_t>() : nullptr, &depth, &why))
+		uint32_t n_wide = 0;
+		if (!mirt_gpu::build_lbvh(c->stream, c->spheres.as<float4>(), n_spheres, half ? nullptr : c->recs.as<float>(), half ? c->recs.as<uint32_t>() : nullptr, &depth, &why,
+		                          want_wide ? c->recs_wide.as<uint32_t>() : nullptr, &n_wide))
 			return fail(c, MIRT_ERR_HIP, "GPU BVH build: %s", why.c_str());
 		if (depth >= kStack) return fail(c, MIRT_ERR_ARG, "GPU-built BVH is %u levels deep (limit %u): set policy.gpu_build = 0 for this scene", depth, kStack);
+		if (want_wide && n_wide && 3u * (depth / 2u) < kStack) { wide = true; wide_gpu = true; n_recs = n_wide; }     // depth counts the leaf level: depth / 2 = wide levels, rounded up
 	} else {
 		std::vector<mirt_bvh_node> own; std::vector<uint32_t> prim_of_slot;
 		const bool caller_tree = c->policy.reference_tree || n_spheres == 0;
@@ -648,7 +653,7 @@ int mirt_set_scene(mirt_ctx* c, const mirt_sphere* geometry, const mirt_sphere* 
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 
 	SceneDev& s = c->scene;
-	s.recs = c->recs.as<float4>(); s.spheres = c->spheres.as<float4>(); s.prim_mat = c->prim_mat.as<int32_t>();
+	s.recs = wide_gpu ? c->recs_wide.as<float4>() : c->recs.as<float4>(); s.spheres = c->spheres.as<float4>(); s.prim_mat = c->prim_mat.as<int32_t>();
 	s.light_sphere = c->light_sphere.as<float4>(); s.light_emit = c->light_emit.as<float4>();
 	s.mat_albedo = c->mat_albedo.as<float4>(); s.mat_emission = c->mat_emission.as<float4>();
 	s.hdri = c->hdri.as<float4>();
