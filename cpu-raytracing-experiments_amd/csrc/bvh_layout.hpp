@@ -14,8 +14,8 @@
 // first_id, first_id+1 for the same reason).
 //
 // DEFAULT LAYOUT: 4-wide binary16 records (64 B: a node and its inner children, build_wide_half_records below) whenever binary16
-// is precise enough and the tree is not too deep; the child-pair records described here remain for GPU-built trees, deep trees
-// and f32 planes.
+// is precise enough and the tree is not too deep (from the host builder here or from lbvh_build.hip); the child-pair records
+// described here remain for deep trees and f32 planes.
 //
 // Half-precision variant (32 B per record, used when it is precise enough for the scene): the same twelve planes as
 // IEEE binary16, lo planes rounded toward -inf and hi planes toward +inf so the boxes only ever grow:

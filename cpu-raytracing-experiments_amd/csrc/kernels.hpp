@@ -805,7 +805,7 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, 
 		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);   // > 32768 records or spheres: never all in LDS
 		else if (all) trace_persistent<MODE, COUNT, true, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 		else trace_persistent<MODE, COUNT, false, true, true, true>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
-	} else if (sc.half_boxes) {                                              // binary 32-B records: GPU-built trees, trees too deep for the wide layout
+	} else if (sc.half_boxes) {                                              // binary 32-B records: trees too deep for the wide layout
 		if (!sc.stack16) trace_persistent<MODE, COUNT, false, true, false, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 		else if (all) trace_persistent<MODE, COUNT, true, true, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
 		else trace_persistent<MODE, COUNT, false, true, true, false>(sc, tl, q, n, work_next, fat, c_nodes, c_spheres, load_ray, store_result, col);
