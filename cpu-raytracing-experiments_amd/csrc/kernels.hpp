@@ -69,7 +69,7 @@ struct StreamBuf {
 	float *rr, *rg, *rb;        // radiance
 	                            // (`pdf` has no plane: Closure::pdf of the sampled direction is (1/pi) max(0, dir.z) of the WORLD-space dir
 	                            //  (Q8, Renderer.hpp:386,401), a function of the stored direction, recomputed by the bounce that needs it)
-	uint32_t* path;             // (batch slot << 24) | local pixel index (tile_local*256 + ID); stands in for pixelID + seed[]
+	uint32_t* path;             // (batch slot << FrameParams::pix_bits) | local pixel index (tile_local*256 + ID); stands in for pixelID + seed[]
 };
 // RayStream<>::ShadowStream, DataStreams.hpp:113-126, plus the deferred-add operands.  A record is 32 B for the common case
 // (dir, tfar, NEE radiance, destination): the origin is the surviving ray's own (read from the next stream through `dest`;
@@ -89,6 +89,8 @@ struct FrameParams {
 	uint32_t run_tiles;         // the context owns runs of run_tiles consecutive LaunchIndices, stride_tiles apart (interleaved tile rows,
 	uint32_t stride_tiles;      // mirt_set_tile_rows); stride_tiles = 0: one contiguous range (mirt_set_tile_range)
 	uint32_t n_pix;             // local pixels = local tiles * 256
+	uint32_t pix_bits;          // a path id is (batch slot << pix_bits) | local pixel, below 2^30: the fewer pixels a context owns, the more
+	uint32_t pix_mask;          // accumulations fit a batch ((1 << pix_bits) - 1)
 	uint32_t acc_base;          // `accumulations` before this batch
 	uint32_t batch_n;           // accumulations in flight in this batch
 	uint32_t idx_base;          // where the paths' radiance is added (accum_index): straight into the accumulator (idx_base = acc_base,
@@ -776,7 +778,7 @@ MIRT_DI void primary_ray(const FrameParams& fp, uint32_t i, uint32_t& path, floa
 	const float s0 = rand_unit_float(rng);
 	const float s1 = rand_unit_float(rng);
 	const f3 d = camera_ray_dir(fp.cam, x, y, s0, s1);
-	path = (slot << 24) | pix;
+	path = (slot << fp.pix_bits) | pix;
 	dx = d.x; dy = d.y; dz = d.z;
 }
 // The same rays written out as a stream (mirt_debug_raygen only).
@@ -818,13 +820,13 @@ MIRT_DI void trace_queue(const SceneDev& sc, const TraceLds tl, const Queue& q, 
 // ------------------------------------------------------------------------------------------------
 // Accumulator addressing + the deferred shadow-ray adds
 // ------------------------------------------------------------------------------------------------
-MIRT_DI size_t accum_index(uint32_t acc_base, uint32_t buckets, uint32_t path) {
-	const uint32_t slot = (path >> 24) & 0x7fu;
-	const uint32_t pix = path & 0xffffffu;
+MIRT_DI size_t accum_index(uint32_t acc_base, uint32_t buckets, uint32_t pix_bits, uint32_t path) {      // path: below 2^30 (no flag bits)
+	const uint32_t slot = path >> pix_bits;
+	const uint32_t pix = path & ((1u << pix_bits) - 1u);
 	const uint32_t bucket = (acc_base + slot + 1u) % buckets;               // Renderer.hpp:82
 	return (static_cast<size_t>(pix >> 8) * buckets + bucket) * 3u * kTileSize + (pix & 255u);
 }
-MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) { return accum_index(fp.idx_base, fp.idx_buckets, path); }
+MIRT_DI size_t accum_index(const FrameParams& fp, uint32_t path) { return accum_index(fp.idx_base, fp.idx_buckets, fp.pix_bits, path); }
 MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, float g, float b) {     // Renderer.hpp:427-429
 	// (pixel, bucket) is unique within a batch and batches are stream-ordered: plain read-modify-write, no atomics,
 	// and each bucket sees its adds in accumulation order exactly like the reference.
@@ -841,12 +843,12 @@ MIRT_DI void accumulate_add(float* __restrict__ accum, size_t idx, float r, floa
 //     earlier samples): R and E travel in the record and (R + S) + E is formed here.
 // occ != nullptr (mirt_debug_trace_shadow): only the occlusion flag is stored.
 constexpr uint32_t kDestFull = 0x40000000u;
-constexpr uint32_t kDestSlot = 0x3fffffffu;     // stream slots stay below 2^30 (capacity check in mirt_capi.hip); path ids use bits 0-29 too (slot < 64)
+constexpr uint32_t kDestSlot = 0x3fffffffu;     // stream slots stay below 2^30 (capacity check in mirt_capi.hip); path ids use bits 0-29 too (batch slot << pix_bits | pixel)
 struct ShadowSink {
 	float *rr, *rg, *rb;        // radiance planes of the stream k_shade reads next
 	const float *px, *py, *pz;  // its origin planes (shared with the shadow rays of the surviving paths)
 	float* accum;
-	uint32_t acc_base, buckets;
+	uint32_t acc_base, buckets, pix_bits;
 	uint32_t* occ;
 };
 MIRT_DI void shadow_origin(const ShadowBuf& sh, const ShadowSink& sink, uint32_t i, float& px, float& py, float& pz) {
@@ -865,11 +867,11 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 		const f3 E{ sh.er[i], sh.eg[i], sh.eb[i] };
 		if (!occluded) { R.x += sh.sr[i]; R.y += sh.sg[i]; R.z += sh.sb[i]; }
 		R.x += E.x; R.y += E.y; R.z += E.z;
-		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), R.x, R.y, R.z);
+		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, sink.pix_bits, dest & ~kDestAccum), R.x, R.y, R.z);
 		else { sink.rr[dest] = R.x; sink.rg[dest] = R.y; sink.rb[dest] = R.z; }
 	} else if (!occluded) {
 		const f3 S{ sh.sr[i], sh.sg[i], sh.sb[i] };
-		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, dest & ~kDestAccum), S.x, S.y, S.z);   // word = R + S
+		if (dest & kDestAccum) accumulate_add(sink.accum, accum_index(sink.acc_base, sink.buckets, sink.pix_bits, dest & ~kDestAccum), S.x, S.y, S.z);   // word = R + S
 		else { sink.rr[dest] += S.x; sink.rg[dest] += S.y; sink.rb[dest] += S.z; }
 	}
 }
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, Frame
 		if (i < total) {
 			uint32_t path; float dx, dy, dz;
 			primary_ray(fp, i, path, dx, dy, dz);
-			const uint32_t pix = path & 0xffffffu;
+			const uint32_t pix = path & fp.pix_mask;
 			const uint32_t cnt = cand[pix];
 			if (cnt == kCandOverflow) fall_back = true;
 			else {
@@ -1195,8 +1197,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 				const float4 em = s_emission[mat];
 				const float4 alb = s_albedo[mat];
 				const bool is_emissive = max_sel(em.x, max_sel(em.y, em.z)) > MIRT_FLT_EPSILON;
-				const uint32_t acc = fp.acc_base + (path >> 24) + 1u;
-				const uint32_t seed = path_seed(fp, path & 0xffffffu);
+				const uint32_t acc = fp.acc_base + (path >> fp.pix_bits) + 1u;
+				const uint32_t seed = path_seed(fp, path & fp.pix_mask);
 
 				// NEXT EVENT ESTIMATION, Renderer.hpp:247-298
 				if (fp.mis) {

@@ -101,7 +101,7 @@ struct mirt_ctx {
 	DeviceBuffer counters;           // DevCounters
 	std::vector<PipeSlot> slots;     // batches in flight (policy.streams)
 	uint64_t planned_for = 0;        // local pixel count batch_mem_cap was planned for (0 = plan again)
-	uint32_t batch_mem_cap = 64;     // accumulations per batch the device memory allows (lowered by ensure_streams when the plan does not fit)
+	uint32_t batch_mem_cap = 256;     // accumulations per batch the device memory allows (lowered by ensure_streams when the plan does not fit)
 	uint32_t capacity = 0;           // rays per stream plane (= kSegs * seg_cap)
 	uint32_t seg_cap = 0;            // slots per queue segment
 	uint32_t arena_bounces = 0;
@@ -128,7 +128,7 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 }
 #define HIP_TRY(ctx, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
 
-// Accumulations traced together as one batch (path id = (slot << 24) | pixel; the slot keeps bits 30 and 31 free, hence <= 64).
+// Accumulations traced together as one batch (path id = (slot << pix_bits) | pixel below 2^30: bits 30 and 31 stay free for flags).
 // Every launch of a batch ends in a tail while its longest rays finish and starts with the staging of the tree top, so
 // launches want to be LARGE — and 288 GB of HBM is there to be used for ray streams (180 B per ray and batch in flight).
 // Measured on one MI355X (Mray/s; accumulations per batch x batches in flight on separate HIP streams):
@@ -136,20 +136,24 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 //   one eighth of cfg4:     16 x 3: 4367  32 x 3: 4981  64 x 3: 5103   64 x 1: 5498
 //   cfg3 1920x1088 S(10000): 16 x 3: 5378  32 x 3: 5753  64 x 3: 5700  64 x 1: 6354
 //   cfg2 1024^2 S(1000):    32 x 3: 7510  64 x 3: 8011  64 x 1: 7654
-// Hence: aim at 512 M primary rays per batch (at most 64 accumulations, at most what the free device memory holds), and keep
+// Hence: aim at 512 M primary rays per batch (at most max_slots() accumulations, at most what the free device memory holds), and keep
 // ONE batch in flight once a batch carries 96 M primary rays or more — launches that fill the chip for milliseconds gain
 // nothing from sharing it with another stream's kernels and lose to the interleaving — three below that (other batches fill the tails).
-constexpr uint32_t kMaxBatch = 64;          // slot < 64 keeps bit 30 of a path id free (kDestFull)
+constexpr uint32_t kMaxBatch = 256;         // upper limit of accumulations per batch; a context's own limit is what its path ids hold (max_slots)
 constexpr uint64_t kBatchRays = 512ull << 20;
 constexpr uint64_t kSerialRays = 96ull << 20;
 constexpr size_t kStreamPlanes = 2 * 13 + 2 + 17;      // two ray streams, hit (tfar, prim), shadow stream: 4-byte planes per ray of capacity
+// Path id = (batch slot << pix_bits) | local pixel, below 2^30 (bits 30 and 31 of the words that carry it are flags): a context that owns
+// all 2^24 pixels of a 4096^2 image has room for 64 slots, one that owns an eighth of it (a rank of an 8-GPU run) for 512.
+uint32_t pix_bits_of(const mirt_ctx* c) { uint32_t b = 8; while ((1ull << b) < static_cast<uint64_t>(c->n_tiles) * kTileSize) b++; return b; }
+uint32_t max_slots(const mirt_ctx* c) { return std::min<uint32_t>(kMaxBatch, 1u << (30u - std::min<uint32_t>(pix_bits_of(c), 24u))); }
 uint32_t batch_floor(const mirt_ctx* c) { return std::max<uint32_t>(std::min<uint32_t>(c->policy.buckets, 5u), 1u); }   // the reference's natural group: five calls, five buckets
 uint32_t batch_limit(const mirt_ctx* c) {
-	if (c->policy.max_batch) return std::min(c->policy.max_batch, kMaxBatch);
+	if (c->policy.max_batch) return std::min(c->policy.max_batch, max_slots(c));
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
 	if (n_pix == 0) return 1;
 	const uint64_t b = std::max<uint64_t>((kBatchRays + n_pix / 2) / n_pix, batch_floor(c));
-	return static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(b, kMaxBatch), std::max<uint32_t>(c->batch_mem_cap, 1u)));
+	return static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(b, max_slots(c)), std::max<uint32_t>(c->batch_mem_cap, 1u)));
 }
 // Paths add straight into the accumulator only when a batch cannot touch a (pixel, bucket) word twice and no other
 // batch is in flight; otherwise every batch adds into its own contribution buffer, merged in accumulation order.
@@ -338,6 +342,7 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	fp.run_tiles = c->run_tiles ? c->run_tiles : 1u;
 	fp.stride_tiles = c->stride_tiles;
 	fp.n_pix = c->n_tiles * kTileSize;
+	fp.pix_bits = pix_bits_of(c); fp.pix_mask = (1u << fp.pix_bits) - 1u;
 	fp.acc_base = acc_base;
 	fp.batch_n = batch_n;
 	fp.idx_base = acc_base;
@@ -416,7 +421,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const FatList fc{ fat_n_closest + bounce, sl.fat.as<uint32_t>(), kFatCapacity };
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
-		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, nullptr };
+		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, fp.pix_bits, nullptr };
 		  auto launch_trace = [&](auto kernel, auto fat_kernel) {
 		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, stream_queue(bounce), work_next + bounce,
 		                       sl.shadow_buf, sink, sq, sc_work, fc, fs, ctr);

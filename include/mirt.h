@@ -75,7 +75,8 @@ typedef struct mirt_policy {
 	uint32_t use_bvh;       /* #define USEBVH, BVH.hpp:307 (reference ships 0 = brute force) */
 	uint32_t count_traffic; /* 1: kernels also count BVH nodes / spheres visited (slower; for the roofline's algorithmic bytes) */
 	uint32_t profile;       /* 1: bracket every kernel launch with HIP events (mirt_get_kernel_times) */
-	uint32_t max_batch;     /* Accumulate() calls traced together as one batch (1..64); 0 = auto, about 32 M primary rays per batch.
+	uint32_t max_batch;     /* Accumulate() calls traced together as one batch (1..256, at most what the context's path ids hold: 2^30 / its pixel count
+	                           rounded up to a power of two); 0 = auto, about 512 M primary rays per batch within the free device memory.
 	                           Results do not depend on it: adds reach every bucket in accumulation order. */
 	uint32_t reference_tree;/* 0 (default): traverse a GPU-internal SAH tree built over the same BVH-order prims; 1: traverse the caller's
 	                         * nodes as handed over.  Results are identical either way (DESIGN.md "Traversal semantics"); read at mirt_set_scene. */

@@ -541,15 +541,24 @@ def test_batches_larger_than_the_bucket_count(mirt, streams):
     sc = mirt.scene.synthetic(1000, ambient=0.5)
     o = ob.Oracle(sc, max_bounces=5, trav_mode=ob.TRAV_BRUTE); o.Resize(192, 96); o.Accumulate(23)
     want, wc = o.accumulator(), o.counters()
-    for max_batch in (0, 1, 3, 5, 7, 16, 64):
+    for max_batch in (0, 1, 3, 5, 7, 16, 64, 200):
         r = mirt.Renderer(sc, max_bounces=5, use_bvh=True, streams=streams, max_batch=max_batch); r.Resize(192, 96)
         eff = r.get_policy()
-        assert eff["max_batch"] == (max_batch or 64) and eff["streams"] == streams      # 0 = auto: 32 M rays / 18 k pixels, capped at 64
+        assert eff["max_batch"] == (max_batch or 256) and eff["streams"] == streams      # 0 = auto: 512 M rays / 18 k pixels, capped at 256 (path ids: slot << 15 | pixel)
         r.Accumulate(9); r.Accumulate(14)
         assert_same(r.accumulator(), want, f"max_batch={max_batch} streams={streams}")
         c = r.counters()
         assert c["rays"] == wc["rays"] and c["terminated"] == wc["terminated"] and c["terminated"] + c["dropped"] == 23 * 192 * 96   # every path accounted for
         r.close()
+    # a context with few pixels has room for many batch slots in its path ids: 150 accumulations of a 64x48 image as ONE batch
+    sc = mirt.scene.default9()
+    o = ob.Oracle(sc, max_bounces=6, trav_mode=ob.TRAV_BRUTE); o.Resize(64, 48); o.Accumulate(150)
+    r = mirt.Renderer(sc, max_bounces=6, use_bvh=True, streams=streams); r.Resize(64, 48)
+    assert r.get_policy()["max_batch"] == 256
+    r.AccumulateAsync(150); r.Synchronize()
+    assert_same(r.accumulator(), o.accumulator(), f"150 accumulations in one batch, streams={streams}")
+    assert r.Render(); assert_same(r.GetFrame(), o.Render(), "its frame")
+    r.close()
 
 
 def test_stream_pipelining_does_not_change_results(mirt):
