@@ -185,7 +185,7 @@ def main():
                     help="BASELINE config (default cfg4, the one the metric is quoted on). Every config keeps its own fixed image and splits its tile rows over the ranks")
     ap.add_argument("--spp", type=int, default=64, help="accumulations (Renderer::Accumulate() calls) per step")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
-    ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 32 M primary rays)")
+    ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 512 M primary rays, at most 256 calls)")
     ap.add_argument("--aux-steps", type=int, default=2, help="steps of the roofline passes (per-kernel HIP-event timing, counting replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the per-kernel timing and counting passes (roofline becomes null)")
@@ -421,7 +421,8 @@ def main():
                                     f"(primary+{cfg['max_bounces'] - 1} bounces), {cfg['buckets']} buckets, {spp} accumulations/step; fixed image, tile rows split over the GPUs"),
                        "image": f"{width}x{height}", "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
                        "parallelism": f"tile rows interleaved over {world} GPUs, one RCCL gather" if world > 1 else "single GPU", "batches_in_flight": n_streams,
-                       "accumulations_per_batch": min(batch, spp),
+                       "accumulations_per_batch": min(batch, spp * K),     # the K steps are issued with mirt_accumulate_async: a batch may span steps
+                       "accumulations_per_batch_limit": batch,
                        "primary_rays": "the jittered camera rays of a pixel share one cone traversal per batch that lists the spheres they can hit; every ray is then "
                                        "intersected with its pixel's list by the reference's arithmetic (policy.trace_primary_rays = 0, bit-identical results)"},
             "value_with_every_primary_ray_walking_the_tree": value_walk,
