@@ -31,10 +31,11 @@ while time.time() < t_end:
     w, h = int(rng.choice([64, 96, 208, 512, 1024])), int(rng.choice([48, 64, 160, 256, 768]))
     mb, buckets, mis = int(rng.integers(1, 10)), int(rng.choice([1, 3, 5, 8, 16])), bool(rng.random() < 0.8)
     spp = int(rng.integers(1, 24))
+    if w * h <= 96 * 64 and rng.random() < 0.3: spp = int(rng.integers(65, 200))      # a small image leaves room for many batch slots: one batch of up to 199 accumulations
     ref = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, mis=mis, use_bvh=False, streams=1, max_batch=int(rng.choice([0, 1, 5])))
     ref.Resize(w, h); ref.Accumulate(spp); want = ref.accumulator(); cw = ref.counters(); ref.close()
     kw = dict(gpu_build=bool(rng.random() < 0.5), reference_tree=bool(rng.random() < 0.2), allow_half_boxes=bool(rng.random() < 0.7),
-              streams=int(rng.choice([0, 1, 2, 3, 5])), max_batch=int(rng.choice([0, 0, 1, 3, 7, 32, 64])), trace_primary_rays=bool(rng.random() < 0.15))
+              streams=int(rng.choice([0, 1, 2, 3, 5])), max_batch=int(rng.choice([0, 0, 1, 3, 7, 32, 64, 200])), trace_primary_rays=bool(rng.random() < 0.15))
     r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, mis=mis, use_bvh=True, **kw); r.Resize(w, h)
     left = spp
     while left:                                              # split the calls randomly, mixing sync and async
