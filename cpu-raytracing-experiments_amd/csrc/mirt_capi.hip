@@ -357,7 +357,7 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	return fp;
 }
 
-// One batch = up to batch_limit() consecutive Accumulate() calls traced together (path id = (slot << 24) | pixel).
+// One batch = up to batch_limit() consecutive Accumulate() calls traced together (path id = (slot << pix_bits) | pixel).
 // Consecutive accumulation indices land in buckets (acc % buckets, Renderer.hpp:82), and the ORDER of the adds into a
 // bucket word is part of the result.  With at most `buckets` accumulations per batch and one batch at a time every
 // (pixel, bucket) word is touched once per batch and paths add straight into the accumulator.  Otherwise each batch adds

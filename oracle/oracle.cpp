@@ -742,7 +742,7 @@ static void traverse_stream_shadow(const BVH& bvh, ShadowStream& in, size_t size
 	}
 }
 
-// mode 2: robust per-ray traversal — CPU twin of traverse_bvh() in csrc/kernels.hpp.
+// mode 2: robust per-ray traversal — CPU twin of node_step() / node_step_wide() / leaf_step() in csrc/kernels.hpp.
 // Boxes: every leaf box is the sphere's bbox grown by pad = pad_rel * (max|centre coord| + radius)
 // and rounded outward; inner boxes are unions of their children.  The padding absorbs the rounding of
 // the slab test and the "fuzz" of the reference's sphere test (BVH.hpp:251-267), so a sphere the

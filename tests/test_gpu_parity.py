@@ -535,7 +535,7 @@ def test_batching_and_call_splitting_do_not_change_results(mirt):
 
 @pytest.mark.parametrize("streams", [1, 3])
 def test_batches_larger_than_the_bucket_count(mirt, streams):
-    """A batch may carry more accumulations than there are buckets (default: about 32 M primary rays per batch): paths add
+    """A batch may carry more accumulations than there are buckets (default: about 512 M primary rays per batch, at most 256 accumulations): paths add
     into a per-slot contribution buffer and the merge applies the slots to their buckets in accumulation order, so every
     batch size gives the oracle's accumulator bit for bit — including sizes that do not divide the bucket count or the call."""
     sc = mirt.scene.synthetic(1000, ambient=0.5)
