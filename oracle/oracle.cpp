@@ -962,8 +962,8 @@ static inline bool traverse_ray_shadow(const BVH& bvh, const std::vector<Sphere>
 	}
 }
 
-// diagnostic (orc_wide_stats): what the same walk would cost on the tree collapsed to 4-wide nodes — every inner node
-// absorbs its inner children, the hit children of a wide node are visited nearest first, leaves are stack items as above.  Counts
+// diagnostic (orc_wide_stats): what the same walk would cost on the tree collapsed to 4-wide (or 8-wide) nodes — every
+// inner node absorbs its inner children (and theirs), the hit children of a wide node are visited nearest first, leaves are stack items as above.  Counts
 // wide-node visits (= dependent record fetches per ray) and box tests; results are discarded.
 static std::atomic<uint64_t> g_wide[6];           // closest: rays, visits, boxes; shadow: rays, visits, boxes
 static bool g_wide_on = false;
@@ -983,15 +983,20 @@ static void wide_walk(const BVH& bvh, const std::vector<Sphere>& prims, float px
 			if (anyhit) { if (sphere_occludes(prims[p], px, py, pz, dx, dy, dz, tfar)) break; }
 			else sphere_closest_tie(prims[p], static_cast<int32_t>(p), px, py, pz, dx, dy, dz, &tfar, &primID);
 		} else {
-			uint32_t kids[4]; int nk = 0;
-			for (uint32_t c = n.first_id; c <= n.first_id + 1; c++) {
-				if (bvh.nodes[c].prim_count == 0) { kids[nk++] = bvh.nodes[c].first_id; kids[nk++] = bvh.nodes[c].first_id + 1; }
-				else kids[nk++] = c;
+			uint32_t kids[8]; int nk = 0;
+			kids[nk++] = n.first_id; kids[nk++] = n.first_id + 1;
+			for (int level = 0; level < (g_wide_variant == 2 ? 2 : 1); level++) {         // absorb the inner kids once (4-wide) or twice (8-wide)
+				uint32_t next[8]; int nn = 0;
+				for (int k = 0; k < nk; k++) {
+					if (bvh.nodes[kids[k]].prim_count == 0) { next[nn++] = bvh.nodes[kids[k]].first_id; next[nn++] = bvh.nodes[kids[k]].first_id + 1; }
+					else next[nn++] = kids[k];
+				}
+				nk = nn; for (int k = 0; k < nk; k++) kids[k] = next[k];
 			}
 			visits++; boxes += static_cast<uint64_t>(nk);
-			float t[4]; uint32_t hit[4]; int nh = 0;
+			float t[8]; uint32_t hit[8]; int nh = 0;
 			for (int k = 0; k < nk; k++) { float tn; if (slab_test(rs, bvh.padded[kids[k]], tfar, &tn)) { t[nh] = tn; hit[nh] = kids[k]; nh++; } }
-			if (g_wide_variant == 0) { for (int a = 1; a < nh; a++) for (int b = a; b > 0 && t[b] < t[b - 1]; b--) { std::swap(t[b], t[b - 1]); std::swap(hit[b], hit[b - 1]); } }
+			if (g_wide_variant != 1) { for (int a = 1; a < nh; a++) for (int b = a; b > 0 && t[b] < t[b - 1]; b--) { std::swap(t[b], t[b - 1]); std::swap(hit[b], hit[b - 1]); } }
 			else { int m = 0; for (int a = 1; a < nh; a++) if (t[a] < t[m]) m = a; if (nh) { std::swap(t[0], t[m]); std::swap(hit[0], hit[m]); } }     // nearest first, the rest as stored
 			for (int k = nh - 1; k >= 1; k--) if (sp < 256) stack[sp++] = hit[k];
 			if (nh) { id = hit[0]; continue; }
@@ -1397,7 +1402,8 @@ int orc_set_scene(void* h, const void* geometry, int n, const void* materials, i
 	}
 	return 0;
 }
-void orc_wide_stats(int on, uint64_t* out) { g_wide_on = on != 0; g_wide_variant = on > 1 ? 1 : 0; if (out) for (int i = 0; i < 6; i++) out[i] = g_wide[i]; }
+// on = 1: 4-wide, hit kids sorted; 2: 4-wide, nearest first, the rest as stored; 3: 8-wide, sorted
+void orc_wide_stats(int on, uint64_t* out) { g_wide_on = on != 0; g_wide_variant = on > 1 ? on - 1 : 0; if (out) for (int i = 0; i < 6; i++) out[i] = g_wide[i]; }
 void orc_len_hist(int on, uint64_t* out) { g_len_hist_on = on != 0; if (out) for (int i = 0; i < 16; i++) out[i] = g_len_hist[i]; }
 void orc_set_cone_fuzz(float f) { g_cone_fuzz = f; }
 void orc_set_padding(void* h, float pad_rel) { Oracle& o = *static_cast<Oracle*>(h); bvh_pad(o.accel, o.bvh.prims, pad_rel); if (o.accel_half) bvh_quantize_half(o.accel); }
