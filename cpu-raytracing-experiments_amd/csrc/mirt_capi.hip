@@ -938,9 +938,10 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	HIP_TRY(c, fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
 	uint32_t* misc = cn + 2 * kQueueWords;
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
+	{ Bracket t(c, MIRT_K_TRACE);                                               // policy.profile: the launch is timed like those of a batch (mirt_get_kernel_times)
 	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
 	                   Queue{ cn, 0u }, misc, ShadowBuf{}, ShadowSink{}, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr);
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
@@ -973,9 +974,10 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
 	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
+	{ Bracket t(c, MIRT_K_TRACE);
 	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
 	                   Queue{ cn, 0u }, misc, sh, sink, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>());
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>()); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
