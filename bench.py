@@ -14,11 +14,19 @@ slabs after the timed region (timed separately).  --config cfg2|cfg3|cfg5 select
 value = rays handed to closest-hit traversal by all ranks (Renderer.hpp:165: primary + extension rays; shadow rays are
 reported separately) / max-over-ranks wall time of the K timed steps, inputs resident in HBM, no profiling in that pass.
 
-roofline (N = 1): k_trace, the dominant kernel, is bound by VALU issue, not by HBM (its BVH bytes are served from LDS/L2).
+roofline (rank 0's share of the image for N > 1): k_trace, the dominant kernel, is bound by VALU issue, not by HBM (its BVH bytes are
+served from LDS/L2; north_star's ">= 60 % of the HBM roofline" does not apply to a cache-resident tree — roofline.hbm carries the §8d
+figure and the measured traffic as labelled secondaries).
   * per-kernel durations: HIP events on the launch stream, in a second live pass with one batch in flight (policy.profile);
   * VALU instructions, lane utilisation and HBM bytes (FETCH_SIZE / WRITE_SIZE): measured IN THIS RUN by short child
     processes of this script under `rocprofv3 --pmc` (one batch each, separate passes as MI355X_MICROARCH.md prescribes),
-    started before this process touches the GPU.  Where rocprofv3 is unavailable those fields are null.
+    started by rank 0 before it touches the GPU or joins the process group.  Where rocprofv3 is unavailable those fields are null.
+  * roofline.frac = useful_lane_frac: VALU-issuing SIMD-cycles x the share of lanes doing work in them, over all SIMD-cycles;
+    issue_frac (lanes not weighed) and arithmetic_frac (slab-test and sphere-test lane-operations against the all-FMA vector peak) beside it.
+
+--group: the other host of the multi-GPU path — ONE process drives --gpus N devices through the library's mirt_group_* entry points
+(in-library RCCL gather); same workload and JSON line, no roofline / CPU legs.  Under torch.distributed.run, rank 0 also runs it once as a
+child process after the ranks have released their GPUs and reports it as `group_host` (gather_ms of both hosts in one driver command).
 """
 import argparse
 import csv
@@ -27,6 +35,7 @@ import importlib
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -48,6 +57,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s 
 # binary16-decoding FMAs, integer address arithmetic): the all-FMA rate is not reachable by a traversal, the issue slots are.
 VALU_PEAK_GCYC = 256 * 4 * 2.4            # 10^9 SIMD-cycles per second
 VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12
+# arithmetic_frac: the lane-operations a traversal is FOR — slab tests and sphere tests — against the all-FMA vector peak.  Static VALU
+# counts from the ISA listing (`make -C cpu-raytracing-experiments_amd/csrc asm`, profiles/r03/static_counts.txt): one child box of a 4-wide record =
+# 6 v_fma_mix + 3 v_med3 + 3 v_max3 (per-axis enter / leave) + v_max(0) + v_min(tfar) + v_max3 + v_min3 + v_cmp = 17; one closest-hit
+# sphere test (intersect_prims, FMA chain + correctly rounded sqrt + the (dist, index) acceptance) = 31; one any-hit sphere test = 32.
+# Dynamic counts: the kernels' own box / sphere counters (policy.count_traffic), equal to the CPU twin's.
+OPS_PER_BOX, OPS_PER_SPHERE, OPS_PER_SHADOW_SPHERE = 17, 31, 32
 MIX_COUNTERS = "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"
 SQ_COUNTERS = "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY"
 
@@ -75,11 +90,42 @@ def pmc_child(args):
     cfg = dict(mirt.scene.CONFIGS[args.config])
     r = make_renderer(mirt, cfg, 0, streams=1, max_batch=args.max_batch)
     r.Resize(cfg["width"], cfg["height"])
+    if args.tile_rows:                                     # one rank's share of an N-GPU run: tile rows first, first + stride, ...
+        first, stride = (int(v) for v in args.tile_rows.split(","))
+        r.SetTileRows(first, stride)
     batch = r.get_policy()["max_batch"]
     r.Accumulate(batch)
     c = r.counters()
     print(json.dumps({"batch": batch, "rays": c["rays"], "shadow_rays": c["shadow_rays"]}), flush=True)
     r.close()
+
+
+def run_reaped(cmd, timeout, log, **kw):
+    """subprocess.run for the helper processes of this script, each in a session of its own: when the direct child has ended (or run out
+    of time) whatever else it started — rocprofv3 runs the program as a grandchild, and may leave helpers — is signalled through the
+    process group and waited for, so nothing of ours is alive when bench.py ends (BENCH_r02: procs_at_end 1)."""
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    log(f"child pid {p.pid}: {' '.join(cmd[:3])} ...")
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        out, err = "", f"timed out after {timeout}s"
+    finally:
+        for sig in (signal.SIGTERM, signal.SIGKILL):       # the exact process group we created, nothing matched by name
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
+            time.sleep(0.2)
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+    return subprocess.CompletedProcess(cmd, p.returncode if p.returncode is not None else -9, out, err)
 
 
 def run_pmc_pass(counters, args, log):
@@ -90,8 +136,10 @@ def run_pmc_pass(counters, args, log):
     out_dir = tempfile.mkdtemp(prefix="mirt_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", *counters.split(), "--output-format", "csv", "-d", out_dir, "--",
            sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", args.config, "--max-batch", str(args.max_batch)]
+    if getattr(args, "share", None):
+        cmd += ["--tile-rows", args.share]
     try:
-        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        p = run_reaped(cmd, 240, log, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         info = None
         for line in p.stdout.splitlines():
             if line.startswith("{") and '"batch"' in line:
@@ -129,8 +177,10 @@ def collect_pmc(args, log):
         return None
     out["sq"], out["child"] = sq
     # TCC: FETCH_SIZE takes 3 of the 4 slots, WRITE_SIZE 2 -> separate passes; GRBM: the clock the chip held; then the VALU instruction mix
-    for name, counters in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("mix", MIX_COUNTERS),
-                           ("vmem", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE")):
+    passes = [("mix", MIX_COUNTERS), ("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE")]
+    if not getattr(args, "share", None):                   # the clock and the L1 gather path: single-GPU runs only (the other ranks are waiting)
+        passes += [("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE"), ("vmem", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE")]
+    for name, counters in passes:
         r = run_pmc_pass(counters, args, log)
         out[name] = r[0] if r else None
     log(f"pmc passes took {time.perf_counter() - t0:.1f}s")
@@ -141,35 +191,43 @@ def collect_pmc(args, log):
 def cpu_baseline(mirt, cfg, log):
     """The reference's own CPU path as restated in oracle/ (the reference itself cannot be built here): stream-BVH traversal
     (BVH.hpp:320-358) with the AVX2 8-ray sphere kernel, tiles over the host threads of this job — on a BOUNDED sample: the same
-    scene, camera and policy rendered at a reduced resolution (rays/s does not depend on the pixel count)."""
+    scene, camera and policy rendered at a reduced resolution (rays/s does not depend on the pixel count), at least 4 accumulations
+    (SURVEY.md §8d), sized by a short probe to about 15 s of CPU work."""
     import oracle_binding as ob
-    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # the GPU box gives a 1-GPU job a 16-CPU share
+    hw_threads = os.cpu_count() or 1
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else hw_threads, 16)   # the GPU box gives a 1-GPU job a 16-CPU share
     scene_fn = lambda: mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])   # noqa: E731
     o = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_STREAM_BVH, threads=threads)
-    w, h = min(cfg["width"], 512), min(cfg["height"], 512)
-    o.Resize(w, h)
-    t0 = time.perf_counter(); o.Accumulate(1); t1 = time.perf_counter() - t0
-    n = 1
-    if t1 < 6.0:                                            # grow the sample to ~15 s of CPU work
-        if cfg["width"] >= 1024 and cfg["height"] >= 1024 and t1 * 4 < 20.0:
-            w, h, t1 = 1024, 1024, t1 * 4
-            o.Resize(w, h)
-        n = max(1, min(16, int(15.0 / max(t1, 1e-3))))
-        o.ResetAccumulator()
-        t0 = time.perf_counter(); o.Accumulate(n); t1 = time.perf_counter() - t0
-    rays = o.counters()["rays"]
-    log(f"cpu baseline: {n} accumulation(s) at {w}x{h}, {rays} rays in {t1:.2f}s on {threads} threads")
-    out = {"value": rays / t1 / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
-           "sample": f"{n} accumulation(s) of the same S({cfg['n']}) scene, camera and policy at {w}x{h} px (instead of {cfg['width']}x{cfg['height']}), oracle stream-BVH "
-                     f"mode (reference BVH.hpp:320-358 restated; the reference itself is unbuildable here), {threads}-thread share of the box's host cores"}
+    o.Resize(256, 256)
+    t0 = time.perf_counter(); o.Accumulate(1); probe = max(time.perf_counter() - t0, 1e-3)          # seconds per accumulation of 65536 pixels
+    side = 256
+    for cand in (384, 512, 768, 1024):                      # the largest sample whose 4 accumulations stay below ~20 s
+        if cand <= min(cfg["width"], cfg["height"]) and probe * (cand / 256.0) ** 2 * 4 <= 20.0:
+            side = cand
+    n = int(max(4, min(16, 15.0 / (probe * (side / 256.0) ** 2))))
+    o.Resize(side, side)
+    o.ResetAccumulator()
+    r0 = o.counters()["rays"]
+    t0 = time.perf_counter(); o.Accumulate(n); t1 = time.perf_counter() - t0
+    rays = o.counters()["rays"] - r0
+    log(f"cpu baseline: {n} accumulations at {side}x{side}, {rays} rays in {t1:.2f}s on {threads} of {hw_threads} hardware threads")
+    out = {"value": rays / t1 / 1e6, "unit": "Mray/s", "cores": threads, "host_hardware_threads": hw_threads, "kind": "port",
+           "sample": f"{n} accumulations of the same S({cfg['n']}) scene, camera and policy at {side}x{side} px (instead of {cfg['width']}x{cfg['height']}), oracle stream-BVH "
+                     f"mode (reference BVH.hpp:320-358 restated; the reference itself is unbuildable here), {threads} threads = this job's share of the box's {hw_threads} hardware threads"}
     o.close()
     try:    # the reference AS SHIPPED traverses nothing (#define USEBVH false, BVH.hpp:307): brute force over all spheres (SURVEY.md §8d asks for both)
         b = ob.Oracle(scene_fn(), max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], trav_mode=ob.TRAV_BRUTE, threads=threads)
-        win = 256 if cfg["n"] <= 2000 else 128 if cfg["n"] <= 20000 else 48
-        b.Resize(win, win)
-        t0 = time.perf_counter(); b.Accumulate(2); dtb = time.perf_counter() - t0
-        out["as_shipped_brute_force"] = {"value": b.counters()["rays"] / dtb / 1e6, "unit": "Mray/s", "cores": threads,
-                                         "sample": f"2 accumulations at {win}x{win} px of the same scene and camera (USEBVH false: every ray tests all {cfg['n']} spheres)"}
+        b.Resize(32, 32)
+        t0 = time.perf_counter(); b.Accumulate(1); probe = max(time.perf_counter() - t0, 1e-4)      # per accumulation of 1024 pixels
+        win = 32
+        for cand in (48, 64, 96, 128, 192, 256):
+            if probe * (cand / 32.0) ** 2 * 4 <= 6.0:
+                win = cand
+        b.Resize(win, win); b.ResetAccumulator()
+        r0 = b.counters()["rays"]
+        t0 = time.perf_counter(); b.Accumulate(4); dtb = time.perf_counter() - t0
+        out["as_shipped_brute_force"] = {"value": (b.counters()["rays"] - r0) / dtb / 1e6, "unit": "Mray/s", "cores": threads,
+                                         "sample": f"4 accumulations at {win}x{win} px of the same scene and camera (USEBVH false: every ray tests all {cfg['n']} spheres)"}
         b.close()
     except Exception as e:
         log(f"brute-force cpu baseline skipped: {e}")
@@ -190,10 +248,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the per-kernel timing and counting passes (roofline becomes null)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
+    ap.add_argument("--group", action="store_true", help="one process drives --gpus N devices through the library's mirt_group_* entry points (in-library RCCL gather) "
+                    "instead of one process per GPU; MIRT_BENCH_DEVICES=0,0 names the devices explicitly (rehearsal with members sharing a device)")
+    ap.add_argument("--no-group-host", action="store_true", help="N > 1 under torch.distributed.run: skip the child run of the --group host")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--tile-rows", default="", help=argparse.SUPPRESS)      # --pmc-child: "first,stride" = one rank's share of the image
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.group:
+        return group_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -207,9 +271,11 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    # PMC child passes first: nothing in this process has touched the GPU yet
+    # PMC child passes first, on rank 0: nothing in this process has touched the GPU or joined the process group yet (the other ranks wait
+    # in init_process_group).  For N > 1 the child renders rank 0's share of the image (tile rows 0, N, 2N, ...).
     pmc = None
-    if world == 1 and not args.no_pmc and not args.no_counts:
+    if rank == 0 and not args.no_pmc and not args.no_counts:
+        args.share = f"0,{world}" if world > 1 else ""
         pmc = collect_pmc(args, log)
 
     import torch
@@ -337,7 +403,9 @@ def main():
             traced = counts["rays"] + counts["shadow_rays"]
             ab = algorithmic_bytes(counts)
             roofline = {"bound": "valu", "kernel": "k_trace", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "G VALU-issuing SIMD-cycles/s", "frac": None, "traffic": None,
-                        "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz max clock: a VALU instruction issuing on every SIMD in every quad-cycle; achieved = 4 x (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) per second",
+                        "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz max clock: a VALU instruction issuing on every SIMD in every quad-cycle with all 64 lanes at work; issue_achieved = 4 x (SQ_INSTS_VALU - "
+                                           "SQ_ACTIVE_INST_VALU2) per second, achieved = issue_achieved x lane_utilisation; frac = useful_lane_frac (issue_frac: lanes not weighed; arithmetic_frac: box and "
+                                           "sphere tests only, against the all-FMA rate); north_star's HBM roofline is the secondary `hbm` (a cache-resident tree is not HBM-bound)",
                         "launches": tr["launches"], "avg_launch_ms": tr["ms"] / tr["launches"],
                         "measured_with": f"HIP events on the launch stream, second live pass of {aux} step(s) with one batch in flight",
                         "traced_rays_per_launch": traced / tr["launches"],
@@ -359,27 +427,36 @@ def main():
                     ach = busy_per_ray * traced / trace_s / 1e9
                 lane_ach = valu_per_ray * traced * 64.0 / trace_s / 1e12
                 lane_util = q["SQ_THREAD_CYCLES_VALU"] / max(64.0 * q["SQ_ACTIVE_INST_VALU"], 1.0)
-                roofline.update(achieved=ach, frac=(ach / VALU_PEAK_GCYC) if ach else None,
+                issue_frac = (ach / VALU_PEAK_GCYC) if ach else None
+                arith_ops = (OPS_PER_BOX * (counts["nodes"] + counts["shadow_nodes"]) + OPS_PER_SPHERE * counts["spheres"] + OPS_PER_SHADOW_SPHERE * counts["shadow_spheres"])
+                roofline.update(achieved=(ach * lane_util) if ach else None, frac=(issue_frac * lane_util) if ach else None,
+                                unit="G VALU-issuing SIMD-cycles/s, weighted by the share of lanes doing work in them",
+                                useful_lane_frac=(issue_frac * lane_util) if ach else None, issue_frac=issue_frac, issue_achieved=ach,
+                                arithmetic_frac=arith_ops / trace_s / 1e12 / VALU_PEAK_TLANE,
+                                arithmetic={"achieved": arith_ops / trace_s / 1e12, "peak": VALU_PEAK_TLANE, "unit": "Tlane-op/s",
+                                            "ops_per_box": OPS_PER_BOX, "ops_per_sphere": OPS_PER_SPHERE, "ops_per_shadow_sphere": OPS_PER_SHADOW_SPHERE,
+                                            "note": "slab-test and sphere-test VALU lane-operations (static counts from the ISA listing x the kernels' own box / sphere counters) per second "
+                                                    "of k_trace, against the all-FMA vector rate; everything else a traversal executes (fetch, decode, ordering, stack, refill) is overhead here"},
                                 valu_issue_cycles_per_traced_ray=busy_per_ray, valu_wave_instructions_per_traced_ray=valu_per_ray,
                                 simd_cycles_per_valu_instruction=(VALU_PEAK_GCYC * 1e9 * trace_s) / (valu_per_ray * traced),
                                 instruction_mix=({k.replace("SQ_INSTS_VALU_", "").lower(): v / mix["SQ_INSTS_VALU"] for k, v in mix.items() if k.startswith("SQ_INSTS_VALU_")} if mix else None),
                                 dual_issue_share=(2.0 * mix["SQ_ACTIVE_INST_VALU2"] / mix["SQ_INSTS_VALU"]) if mix else None,
                                 salu_per_valu=q["SQ_INSTS_SALU"] / q["SQ_INSTS_VALU"],
-                                lane_utilisation=lane_util, useful_frac=(ach / VALU_PEAK_GCYC * lane_util) if ach else None,
+                                lane_utilisation=lane_util,
                                 wait_share=q["SQ_WAIT_ANY"] / max(q["SQ_WAVE_CYCLES"], 1.0),
                                 lane_instructions={"achieved": lane_ach, "peak": VALU_PEAK_TLANE, "unit": "Tlane-inst/s", "frac": lane_ach / VALU_PEAK_TLANE,
                                                    "note": "against the all-FMA issue rate (one wave64 instruction per 2 cycles per SIMD = the 157.3 TFLOP/s vector peak / 2 flop); "
                                                            "k_trace's mix is ~80 % half-rate instructions (4 cycles), see profiles/r02/valu_rates.txt"},
                                 pmc={"source": pmc["command"], "batch": ch["batch"], "launches": q["launches"], "k_trace_ms_under_pmc": q["us"] / 1e3,
                                      "traced_rays": ch_traced, "SQ_INSTS_VALU": q["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU2_per_inst": (mix["SQ_ACTIVE_INST_VALU2"] / mix["SQ_INSTS_VALU"]) if mix else None},
-                                note="achieved = VALU issue quad-cycles x 4 per traced ray (k_trace dispatches of one batch, this run's rocprofv3 --pmc child passes) x rays traced per "
-                                     "second in the HIP-event pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_frac = frac x lane_utilisation")
+                                note="issue_achieved = VALU issue quad-cycles x 4 per traced ray (k_trace dispatches of one batch, this run's rocprofv3 --pmc child passes) x rays traced per "
+                                     "second in the HIP-event pass; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); frac = useful_lane_frac = issue_frac x lane_utilisation")
                 gr = pmc.get("GRBM_GUI_ACTIVE")
                 if gr and "trace" in gr and gr["trace"]["us"] > 0:
                     # MI355X_MICROARCH.md "DVFS give-back": effective clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
                     ghz = gr["trace"]["GRBM_GUI_ACTIVE"] / 8.0 / (gr["trace"]["us"] * 1e-6) / 1e9
                     roofline["clock_GHz_during_k_trace"] = ghz
-                    roofline["frac_at_that_clock"] = (ach / (256 * 4 * ghz)) if ach else None
+                    roofline["issue_frac_at_that_clock"] = (ach / (256 * 4 * ghz)) if ach else None
                 vm = (pmc.get("vmem") or {}).get("trace")
                 if vm and vm.get("GRBM_GUI_ACTIVE"):
                     # the second unit k_trace leans on: every lane of a node / leaf pass gathers its own 32-B record or 16-B sphere, and a CU's
@@ -432,15 +509,76 @@ def main():
             "gather_ms": gather_ms,
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(mirt, cfg, log)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(mirt, cfg, log)     # rank 0, outside every timed region (the other ranks wait below)
+    r.close()                                              # every rank releases its GPU: streams, accumulator, scene
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        if world > 1 and not args.no_group_host:
+            out["group_host"] = group_host_child(args, world, log)
         print(json.dumps(out), flush=True)
-    r.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def group_host_child(args, world, log):
+    """N > 1: the library's own multi-GPU host (mirt_group_*: one process, ncclCommInitAll, grouped ncclSend / ncclRecv to the first device) on
+    the same N devices, run once as a child process of rank 0 after every rank has released its GPU — so one driver command times the gather of
+    both hosts.  A failure or a time-out of the child is reported, it never takes the bench line with it."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    if os.environ.get("MIRT_BENCH_SHARE_GPU") == "1":
+        env["MIRT_BENCH_DEVICES"] = ",".join(["0"] * world)
+    cmd = [sys.executable, os.path.abspath(__file__), "--group", "--gpus", str(world), "--steps", "1", "--warmup", "1", "--config", args.config, "--spp", str(args.spp),
+           "--max-batch", str(args.max_batch), "--streams", str(args.streams)]
+    p = run_reaped(cmd, 300, log, env=env)
+    for line in p.stdout.splitlines():
+        if line.startswith("{"):
+            d = json.loads(line)
+            return {k: d.get(k) for k in ("value", "unit", "ms_per_step", "gather_ms", "n_gpus", "steps", "warmup", "host", "devices")}
+    return {"error": (p.stderr or "no output")[-400:], "returncode": p.returncode}
+
+
+def group_main(args):
+    """bench.py --group: the same workload through the library's group host — `Renderer<> renderer{scene}` as ONE object for the node
+    (Application.cpp:514), one process driving every device, tile rows interleaved over them, the accumulator slabs gathered to the first
+    device by the library itself (csrc/mirt_group.hip: ncclCommInitAll + a grouped ncclSend / ncclRecv per peer).  value = rays of all
+    devices / wall time of the K steps; gather_ms = device time of the gather incl. the un-interleave."""
+    def log(msg):
+        print(f"[bench --group] {msg}", file=sys.stderr, flush=True)
+    mirt = load_mirt()
+    cfg = dict(mirt.scene.CONFIGS[args.config])
+    devices = [int(v) for v in os.environ["MIRT_BENCH_DEVICES"].split(",")] if os.environ.get("MIRT_BENCH_DEVICES") else list(range(args.gpus))
+    sc = mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])
+    g = mirt.GroupRenderer(sc, devices=devices, max_bounces=cfg["max_bounces"], buckets=cfg["buckets"], mis=True, use_bvh=bool(cfg["use_bvh"]),
+                           max_batch=args.max_batch, streams=args.streams)
+    g.Resize(cfg["width"], cfg["height"])
+    spp, K, W = args.spp, args.steps, args.warmup
+    log(f"{args.config}: {cfg['width']}x{cfg['height']}, S({cfg['n']}), {spp} accumulations/step on devices {devices}")
+    for _ in range(W):
+        g.Accumulate(spp)
+    rays0 = g.counters()["rays"]
+    g.Synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        g.AccumulateAsync(spp)
+    g.Synchronize()
+    elapsed = time.perf_counter() - t0
+    rays = g.counters()["rays"] - rays0
+    g.Gather()                                             # the one exchange of the path, outside the timed region like the per-process host's
+    gather_ms = g.gather_ms() if len(devices) > 1 else None
+    out = {"metric": "Mray/s (primary+bounce)", "value": rays / elapsed / 1e6, "unit": "Mray/s", "n_gpus": len(devices), "steps": K, "warmup": W,
+           "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "host": "group (one process, mirt_group_*)", "devices": devices,
+           "config": {"workload": (f"{args.config}: {cfg['width']}x{cfg['height']} px, S({cfg['n']}) spheres + SAH BVH, MIS, Policy.max_bounces={cfg['max_bounces']}, "
+                                   f"{cfg['buckets']} buckets, {spp} accumulations/step; fixed image, tile rows interleaved over the devices of one process"),
+                      "image": f"{cfg['width']}x{cfg['height']}", "spp_per_step": spp, "spheres": cfg["n"], "max_bounces": cfg["max_bounces"], "buckets": cfg["buckets"],
+                      "parallelism": f"mirt_group over {len(devices)} devices, in-library RCCL gather" if len(set(devices)) > 1 else f"mirt_group over {len(devices)} members sharing a device (rehearsal: device copies instead of RCCL)"},
+           "rays_per_step": rays / K, "gather_ms": gather_ms, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    g.close()
 
 
 if __name__ == "__main__":

@@ -216,9 +216,11 @@ class Renderer:
         return {name: int(getattr(p, name)) for name, _ in Policy._fields_ if not name.startswith("_")}
 
     def set_policy(self, **kw):
+        p = Policy.from_buffer_copy(self.policy)
         for k, v in kw.items():
-            setattr(self.policy, k, int(v))
-        self._check(self._lib.mirt_set_policy(self._ctx, C.byref(self.policy)))
+            setattr(p, k, int(v))
+        self._check(self._lib.mirt_set_policy(self._ctx, C.byref(p)))
+        self.policy = p                                    # only a policy the library accepted becomes this object's
 
     # -- scene hand-over (Application.cpp:230-234) -------------------------------------------------
     def UpdateScene(self, nodes=None):
@@ -296,7 +298,7 @@ class Renderer:
         self._check(self._lib.mirt_accumulator_floats(self._ctx, C.byref(n)))
         out = np.empty(n.value, dtype=np.float32)
         self._check(self._lib.mirt_read_accumulator(self._ctx, _ptr(out)))
-        return out.reshape(-1, self.policy.buckets, 3, 256)
+        return out.reshape(n.value // (self.policy.buckets * 768), self.policy.buckets, 3, 256)      # (a context may own no tile at all)
 
     def accumulator_device(self):
         p, b = C.c_void_p(), C.c_size_t(0)
@@ -327,7 +329,7 @@ class Renderer:
         return d
 
     def debug_primary_lists(self) -> list:
-        """hist[n] = pixels whose candidate list holds n spheres (0..8), hist[9] = pixels without a list."""
+        """hist[n] = pixels whose candidate list holds n spheres (n = 0..7), hist[8] = 8 or more, hist[9] = pixels without a list."""
         out = (C.c_uint32 * 10)()
         self._check(self._lib.mirt_debug_primary_lists(self._ctx, out))
         return [int(v) for v in out]
@@ -462,12 +464,16 @@ class GroupRenderer:
         self._check(self._lib.mirt_group_accumulator_floats(self._g, C.byref(n)))
         out = np.empty(n.value, dtype=np.float32)
         self._check(self._lib.mirt_group_read_accumulator(self._g, _ptr(out)))
-        return out.reshape(-1, self.policy.buckets, 3, 256)
+        return out.reshape(n.value // (self.policy.buckets * 768), self.policy.buckets, 3, 256)
 
     def counters(self) -> dict:
         c = Counters()
         self._check(self._lib.mirt_group_get_counters(self._g, C.byref(c)))
         return c.as_dict()
+
+    def Gather(self):
+        """The one exchange of the path: every member's accumulator slab to devices[0] (implied by accumulator() and Render())."""
+        self._check(self._lib.mirt_group_gather(self._g))
 
     def gather_ms(self) -> float:
         v = C.c_double(0.0)

@@ -13,7 +13,7 @@
 //   k_shade           Renderer.hpp:169-431 except the shadow-dependent adds; compacts survivors into the next stream and
 //                     NEE candidates into the shadow stream (wave64 ballot + mbcnt prefix sums, one atomic per workgroup)
 //   k_primary_cand /  bounce 0 only (RAY GENERATION + the first Traverse, Renderer.hpp:113-127,165): the camera rays have no stream — a
-//   k_primary_hits    ray is a function of its index — and the up to 64 jittered samples of a pixel share ONE cone traversal that lists
+//   k_primary_hits    ray is a function of its index — and the jittered samples of a pixel (one per accumulation of the batch, up to 256) share ONE cone traversal that lists
 //                     the spheres they can hit; each sample then tests only its pixel's list (kCollect below)
 //
 // Per-path results do not depend on stream slot or scheduling: every random draw is re-derived from
@@ -384,7 +384,7 @@ MIRT_DI bool trav_begin(Trav& t, float px, float py, float pz, float dx, float d
 // ray is finished (stack empty, or ANYHIT occluder found -> occluded = true).
 // MODE: kClosest (Traverse), kAnyHit (Traverse_shadow), kCollect (candidate spheres of a pixel's bundle of camera rays, below).
 constexpr int kClosest = 0, kAnyHit = 1, kCollect = 2;
-// kCollect — what the samples of ONE PIXEL can hit.  Within a batch a pixel is sampled up to 64 times with sub-pixel jitter
+// kCollect — what the samples of ONE PIXEL can hit.  Within a batch a pixel is sampled once per accumulation (up to 256 times) with sub-pixel jitter
 // (Renderer.hpp:117-118); all those camera rays leave cam.pos inside a cone of half-angle rho around the ray through the pixel
 // centre.  Traversing that cone once (the same conservative slab test, widened by rho) and listing the spheres it can touch turns
 // the primary traversal of every sample into a few exact sphere tests (k_primary_hits).  The list is complete for the closest hit:

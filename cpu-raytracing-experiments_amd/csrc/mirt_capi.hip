@@ -146,7 +146,12 @@ constexpr size_t kStreamPlanes = 2 * 13 + 2 + 17;      // two ray streams, hit (
 // Path id = (batch slot << pix_bits) | local pixel, below 2^30 (bits 30 and 31 of the words that carry it are flags): a context that owns
 // all 2^24 pixels of a 4096^2 image has room for 64 slots, one that owns an eighth of it (a rank of an 8-GPU run) for 512.
 uint32_t pix_bits_of(const mirt_ctx* c) { uint32_t b = 8; while ((1ull << b) < static_cast<uint64_t>(c->n_tiles) * kTileSize) b++; return b; }
-uint32_t max_slots(const mirt_ctx* c) { return std::min<uint32_t>(kMaxBatch, 1u << (30u - std::min<uint32_t>(pix_bits_of(c), 24u))); }
+// ... and a stream slot must stay below 2^30 as well (two flag bits in the words that carry it): pixels x slots + the padding of the kSegs queue segments
+uint32_t max_slots(const mirt_ctx* c) {
+	const uint64_t n_pix = std::max<uint64_t>(static_cast<uint64_t>(c->n_tiles) * kTileSize, 1);
+	const uint64_t by_slots = ((1ull << 30) - kSegs * kShadeBlock) / n_pix;
+	return static_cast<uint32_t>(std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(kMaxBatch, 1u << (30u - std::min<uint32_t>(pix_bits_of(c), 24u))), by_slots), 1));
+}
 uint32_t batch_floor(const mirt_ctx* c) { return std::max<uint32_t>(std::min<uint32_t>(c->policy.buckets, 5u), 1u); }   // the reference's natural group: five calls, five buckets
 uint32_t batch_limit(const mirt_ctx* c) {
 	if (c->policy.max_batch) return std::min(c->policy.max_batch, max_slots(c));
@@ -206,22 +211,26 @@ uint64_t streams_bytes(const mirt_ctx* c) {
 	return wanted_slots(c) * (rays * 4u * kStreamPlanes + (uses_contrib(c, wanted_slots(c)) ? rays * 12u : 0u));
 }
 
+// Automatic batch size: as large as kBatchRays asks, but within 80 % of the device memory that is free plus what this context's own ray
+// streams hold already (other contexts and processes may share the device).  Allocates nothing: mirt_get_policy reports the plan before
+// the first launch; ensure_streams re-carves the arena when the plan changed.  Planned once per pixel count (mirt_set_policy resets it
+// when a field the plan depends on changes).
+void plan_batches(mirt_ctx* c) {
+	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
+	if (c->policy.max_batch || n_pix == 0 || c->planned_for == n_pix) return;
+	c->batch_mem_cap = kMaxBatch;
+	size_t free_b = 0, total_b = 0, own = 0;
+	for (const PipeSlot& sl : c->slots) own += sl.arena.bytes + sl.contrib.bytes;
+	if (hipSetDevice(c->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+		while (batch_limit(c) > batch_floor(c) && streams_bytes(c) > (free_b + own) / 5 * 4) c->batch_mem_cap = std::max(batch_limit(c) / 2, batch_floor(c));
+	c->planned_for = n_pix;
+}
+
 // Carve each slot's frame-wide ray streams out of one allocation.
 int ensure_streams(mirt_ctx* c) {
 	const uint64_t n_pix = static_cast<uint64_t>(c->n_tiles) * kTileSize;
 	if (n_pix * batch_limit(c) == 0) return MIRT_OK;
-	if (!c->policy.max_batch && c->planned_for != n_pix) {
-		// automatic batch size: as large as kBatchRays asks, but within 80 % of the device memory that is free once this context's
-		// own streams are released (other contexts and processes may share the device)
-		HIP_TRY(c, sync_all(c));
-		for (PipeSlot& sl : c->slots) { sl.arena.release(); sl.contrib.release(); }
-		c->capacity = 0;
-		c->batch_mem_cap = kMaxBatch;
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-			while (batch_limit(c) > batch_floor(c) && streams_bytes(c) > free_b / 5 * 4) c->batch_mem_cap = std::max(batch_limit(c) / 2, batch_floor(c));
-		c->planned_for = n_pix;
-	}
+	plan_batches(c);
 	const uint64_t cap64 = n_pix * batch_limit(c);
 	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
 	if (cap64 + kSegs * kShadeBlock > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
@@ -369,7 +378,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	FrameParams fp = frame_params(c, c->accumulations, batch_n);
 	const uint32_t nb = c->policy.max_bounces;
 	const uint64_t total = static_cast<uint64_t>(fp.n_pix) * batch_n;
-	if (total == 0) return MIRT_OK;
+	if (total == 0) { c->accumulations += batch_n; return MIRT_OK; }                   // no tile owned (an image below 16 px, a group member beyond the last tile row): ++accumulations over an empty parallel_for, Renderer.hpp:74-75
 	const bool pipelined = c->slots.size() > 1;
 	PipeSlot& sl = c->slots[c->batch_seq % c->slots.size()];
 	hipStream_t st = pipelined ? sl.stream : c->stream;
@@ -474,7 +483,7 @@ int check_ready(mirt_ctx* c) {
 	if (!c) return MIRT_ERR_ARG;
 	if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_set_scene has not been called");
 	if (!c->have_camera) return fail(c, MIRT_ERR_STATE, "mirt_set_camera has not been called");
-	if (c->n_tiles == 0 || c->width == 0) return fail(c, MIRT_ERR_STATE, "mirt_resize has not been called (or no tiles owned)");
+	if (c->width == 0 && c->height == 0) return fail(c, MIRT_ERR_STATE, "mirt_resize has not been called");
 	return MIRT_OK;
 }
 
@@ -713,14 +722,18 @@ int mirt_set_policy(mirt_ctx* c, const mirt_policy* p) {
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, sync_all(c));
 	const bool realloc_acc = p->buckets != c->policy.buckets;
+	// batch size / batches in flight are planned again only when something the plan depends on changes (a toggle like trace_primary_rays
+	// leaves the ray-stream arena, tens of GB, where it is)
+	const bool replan = p->max_batch != c->policy.max_batch || p->streams != c->policy.streams || p->buckets != c->policy.buckets || p->max_bounces != c->policy.max_bounces;
 	c->policy = *p;
-	c->planned_for = 0;                                                                // batch size / batches in flight are planned again at the next launch
+	if (replan) c->planned_for = 0;
 	if (realloc_acc && c->n_tiles) { int r = alloc_accumulator(c); if (r) return r; }
 	return MIRT_OK;
 }
 int mirt_get_policy(const mirt_ctx* c, mirt_policy* p) {
 	if (!c || !p) return MIRT_ERR_ARG;
 	*p = c->policy;
+	plan_batches(const_cast<mirt_ctx*>(c));        // the plan is a cache: made here if no launch has made it yet, so that the values below are the ones launches will use
 	p->max_batch = batch_limit(c);                 // the values in effect where the caller left 0 = auto
 	p->streams = wanted_slots(c);
 	return MIRT_OK;
@@ -782,6 +795,7 @@ int mirt_accumulate_async(mirt_ctx* c, uint32_t n_calls) {
 	if ((r = ensure_streams(c))) return r;
 	// Whole batches are launched now; a remainder waits for more calls (a frame loop that calls this once per frame still gets
 	// full-size launches) and is launched by the next call that needs it: mirt_synchronize, a read, a state change.
+	if (c->n_tiles == 0) { c->accumulations += n_calls; return MIRT_OK; }
 	const uint32_t limit = batch_limit(c);
 	uint64_t total = static_cast<uint64_t>(c->deferred) + n_calls;
 	c->deferred = 0;
@@ -897,6 +911,7 @@ int mirt_get_stream(mirt_ctx* c, void** s) { if (!c || !s) return MIRT_ERR_ARG; 
 int mirt_debug_raygen(mirt_ctx* c, uint32_t accumulations, float* p_xyz, float* dir_xyz) {
 	int r = check_ready(c); if (r) return r;
 	if (!p_xyz || !dir_xyz || accumulations == 0) return fail(c, MIRT_ERR_ARG, "bad arguments");
+	if (c->n_tiles == 0) return fail(c, MIRT_ERR_STATE, "no tiles owned");
 	HIP_TRY(c, hipSetDevice(c->device));
 	if ((r = ensure_streams(c))) return r;
 	const FrameParams fp = frame_params(c, accumulations - 1, 1);
@@ -1006,7 +1021,7 @@ int mirt_debug_math(mirt_ctx* c, int fn, size_t n, const float* in, float* out) 
 int mirt_debug_primary_lists(mirt_ctx* c, uint32_t hist[10]) {
 	int r = check_ready(c); if (r) return r;
 	if (!hist) return fail(c, MIRT_ERR_ARG, "hist is NULL");
-	if (!c->policy.use_bvh || c->scene.n_recs == 0) return fail(c, MIRT_ERR_STATE, "needs policy.use_bvh and a tree");
+	if (!c->policy.use_bvh || c->scene.n_recs == 0 || c->n_tiles == 0) return fail(c, MIRT_ERR_STATE, "needs policy.use_bvh, a tree and at least one tile");
 	{ const int fr = flush_deferred(c); if (fr) return fr; }
 	HIP_TRY(c, hipSetDevice(c->device));
 	if ((r = ensure_streams(c))) return r;

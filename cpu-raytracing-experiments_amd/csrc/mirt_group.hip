@@ -246,29 +246,36 @@ int mirt_group_gather(mirt_group* g) {
 		g->staging[i] = nullptr; g->staging_bytes[i] = 0;
 		if (bytes[i]) { GHIP(g, hipMalloc(&g->staging[i], bytes[i])); g->staging_bytes[i] = bytes[i]; }
 	}
-	hipEvent_t t0, t1;
-	GHIP(g, hipEventCreate(&t0)); GHIP(g, hipEventCreate(&t1));
+	// From here on every failure is recorded in `rc` and the sequence runs to its end: an ncclGroupStart is always matched by its
+	// ncclGroupEnd and both events are destroyed whatever happened in between.
+	int rc = MIRT_OK;
+	auto hstep = [&](hipError_t e, const char* what) { if (rc == MIRT_OK && e != hipSuccess) rc = gfail(g, MIRT_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); return rc == MIRT_OK; };
+	auto nstep = [&](ncclResult_t r, const char* what) { if (rc == MIRT_OK && r != ncclSuccess) rc = gfail(g, MIRT_ERR_HIP, "%s: %s", what, g_rccl.GetErrorString(r)); return rc == MIRT_OK; };
+	hipEvent_t t0 = nullptr, t1 = nullptr;
 	hipStream_t root = static_cast<hipStream_t>(full_stream);
-	GHIP(g, hipEventRecord(t0, root));
-	if (g->distinct) {
+	hstep(hipEventCreate(&t0), "hipEventCreate"); hstep(hipEventCreate(&t1), "hipEventCreate");
+	if (rc == MIRT_OK) hstep(hipEventRecord(t0, root), "hipEventRecord");
+	if (rc == MIRT_OK && g->distinct) {
 		// ncclGather spelled as its point-to-point form (rccl.h:700,722): the root posts one receive per peer, every peer one send;
 		// each transfer rides the xGMI link between that peer and the root
-		GNCCL(g, g_rccl.GroupStart());
-		for (uint32_t i = 1; i < n; i++) {
-			if (!bytes[i]) continue;
-			GHIP(g, hipSetDevice(g->devices[0]));
-			GNCCL(g, g_rccl.Recv(g->staging[i], bytes[i] / sizeof(float), ncclFloat, static_cast<int>(i), g->comms[0], root));
-			GHIP(g, hipSetDevice(g->devices[i]));
-			GNCCL(g, g_rccl.Send(slab[i], bytes[i] / sizeof(float), ncclFloat, 0, g->comms[i], static_cast<hipStream_t>(stream[i])));
+		if (nstep(g_rccl.GroupStart(), "ncclGroupStart")) {
+			for (uint32_t i = 1; i < n && rc == MIRT_OK; i++) {
+				if (!bytes[i]) continue;
+				if (hstep(hipSetDevice(g->devices[0]), "hipSetDevice"))
+					nstep(g_rccl.Recv(g->staging[i], bytes[i] / sizeof(float), ncclFloat, static_cast<int>(i), g->comms[0], root), "ncclRecv");
+				if (rc == MIRT_OK && hstep(hipSetDevice(g->devices[i]), "hipSetDevice"))
+					nstep(g_rccl.Send(slab[i], bytes[i] / sizeof(float), ncclFloat, 0, g->comms[i], static_cast<hipStream_t>(stream[i])), "ncclSend");
+			}
+			const ncclResult_t end = g_rccl.GroupEnd();                              // always: an open group would swallow every later RCCL call of this thread
+			nstep(end, "ncclGroupEnd");
 		}
-		GNCCL(g, g_rccl.GroupEnd());
-		for (uint32_t i = 1; i < n; i++) { GHIP(g, hipSetDevice(g->devices[i])); GHIP(g, hipStreamSynchronize(static_cast<hipStream_t>(stream[i]))); }
-		GHIP(g, hipSetDevice(g->devices[0]));
-	} else {
-		for (uint32_t i = 1; i < n; i++) if (bytes[i]) GHIP(g, hipMemcpyAsync(g->staging[i], slab[i], bytes[i], hipMemcpyDeviceToDevice, root));
+		for (uint32_t i = 1; i < n && rc == MIRT_OK; i++) if (hstep(hipSetDevice(g->devices[i]), "hipSetDevice")) hstep(hipStreamSynchronize(static_cast<hipStream_t>(stream[i])), "hipStreamSynchronize");
+		(void)hipSetDevice(g->devices[0]);
+	} else if (rc == MIRT_OK) {
+		for (uint32_t i = 1; i < n && rc == MIRT_OK; i++) if (bytes[i]) hstep(hipMemcpyAsync(g->staging[i], slab[i], bytes[i], hipMemcpyDeviceToDevice, root), "hipMemcpyAsync");
 	}
 	const size_t quads_per_row = row_bytes / sizeof(float4);
-	for (uint32_t i = 0; i < n; i++) {
+	for (uint32_t i = 0; i < n && rc == MIRT_OK; i++) {
 		const uint32_t rows = static_cast<uint32_t>(bytes[i] / row_bytes);
 		if (!rows) continue;
 		const float4* src = static_cast<const float4*>(i == 0 ? slab[0] : g->staging[i]);
@@ -276,11 +283,13 @@ int mirt_group_gather(mirt_group* g) {
 		const uint32_t grid = static_cast<uint32_t>(std::min<size_t>((total + 255) / 256, 256u * 16u));
 		hipLaunchKernelGGL(k_uninterleave, dim3(grid), dim3(256), 0, root, static_cast<float4*>(full_ptr), src, quads_per_row, rows, i, n);
 	}
-	GHIP(g, hipGetLastError());
-	GHIP(g, hipEventRecord(t1, root));
-	GHIP(g, hipStreamSynchronize(root));
-	float ms = 0.0f; (void)hipEventElapsedTime(&ms, t0, t1); g->last_gather_ms = ms;
-	(void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+	if (rc == MIRT_OK) hstep(hipGetLastError(), "k_uninterleave");
+	if (rc == MIRT_OK) hstep(hipEventRecord(t1, root), "hipEventRecord");
+	if (rc == MIRT_OK) hstep(hipStreamSynchronize(root), "hipStreamSynchronize");
+	if (rc == MIRT_OK) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, t0, t1); g->last_gather_ms = ms; }
+	if (t0) (void)hipEventDestroy(t0);
+	if (t1) (void)hipEventDestroy(t1);
+	if (rc != MIRT_OK) return rc;
 	uint32_t acc = 0;
 	(void)mirt_get_accumulations(g->members[0], &acc);
 	FULL_TRY(g, "mirt_load_accumulator", mirt_load_accumulator(g->full, static_cast<const float*>(full_ptr), 1, acc));   // in place: only `accumulations` changes

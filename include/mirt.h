@@ -75,9 +75,10 @@ typedef struct mirt_policy {
 	uint32_t use_bvh;       /* #define USEBVH, BVH.hpp:307 (reference ships 0 = brute force) */
 	uint32_t count_traffic; /* 1: kernels also count BVH nodes / spheres visited (slower; for the roofline's algorithmic bytes) */
 	uint32_t profile;       /* 1: bracket every kernel launch with HIP events (mirt_get_kernel_times) */
-	uint32_t max_batch;     /* Accumulate() calls traced together as one batch (1..256, at most what the context's path ids hold: 2^30 / its pixel count
-	                           rounded up to a power of two); 0 = auto, about 512 M primary rays per batch within the free device memory.
-	                           Results do not depend on it: adds reach every bucket in accumulation order. */
+	uint32_t max_batch;     /* Accumulate() calls traced together as one batch: 1..256, clamped to what the context's path ids and stream slots hold —
+	                           2^30 / (its pixel count rounded up to a power of two), and pixels x batch + 4096 <= 2^30 (a context that owns all 2^24 pixels of a
+	                           4096 x 4096 image: 63); 0 = auto, about 512 M primary rays per batch within the free device memory.  mirt_get_policy
+	                           reports the value in effect.  Results do not depend on it: adds reach every bucket in accumulation order. */
 	uint32_t reference_tree;/* 0 (default): traverse a GPU-internal SAH tree built over the same BVH-order prims; 1: traverse the caller's
 	                         * nodes as handed over.  Results are identical either way (DESIGN.md "Traversal semantics"); read at mirt_set_scene. */
 	uint32_t streams;       /* batches of accumulations kept in flight on separate HIP streams (0 = default 3, 1 = one kernel at a time).
@@ -86,7 +87,7 @@ typedef struct mirt_policy {
 	uint32_t gpu_build;     /* 1: the GPU-internal traversal tree is built on the GPU at mirt_set_scene (Morton-order LBVH, milliseconds) instead of
 	                         * the host SAH sweep (better tree, 0.3 s per 100 k spheres): for the edit-rebuild loop (Application.cpp:508).  Results
 	                         * are identical either way; ignored with reference_tree = 1 or fewer than 2 spheres.  Read at mirt_set_scene. */
-	uint32_t trace_primary_rays; /* 0 (default): within a batch, the camera rays of a pixel (up to 64 jittered samples) share ONE cone traversal that lists the
+	uint32_t trace_primary_rays; /* 0 (default): within a batch, the camera rays of a pixel (one jittered sample per accumulation of the batch, up to 256) share ONE cone traversal that lists the
 	                         * spheres they can hit; each sample then tests only those, with the reference's arithmetic.  1: every primary ray walks the
 	                         * tree by itself (measurements; the traversal-twin counter checks).  Results are identical either way. */
 	uint32_t _reserved[1];
@@ -262,7 +263,7 @@ int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out
  * bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
 int mirt_debug_info(mirt_ctx* ctx, uint32_t out[8]);
 /* Length histogram of the per-pixel candidate lists of the current scene / camera / size (policy.trace_primary_rays = 0 path):
- * hist[n] = local pixels whose bundle of camera rays can hit n spheres (n = 0..8), hist[9] = pixels without a list (traced normally). */
+ * hist[n] = local pixels whose bundle of camera rays can hit n spheres for n = 0..7, hist[8] = 8 or more (lists hold up to 15), hist[9] = pixels without a list (traced normally). */
 int mirt_debug_primary_lists(mirt_ctx* ctx, uint32_t hist[10]);
 /* Test knob: forbid (0) / allow (1, default) the binary16 records; takes effect at the next mirt_set_scene. */
 int mirt_debug_allow_half_boxes(mirt_ctx* ctx, int allow);

@@ -607,9 +607,9 @@ def test_edge_cases_and_errors(mirt):
         r.set_policy(buckets=0)
     with pytest.raises(mirt.MirtError):
         r.SetTileRange(7, 5)
-    r.Resize(8, 8)                                         # no whole tile: nothing to do, no crash
-    with pytest.raises(mirt.MirtError):
-        r.Accumulate(1)
+    r.Resize(8, 8)                                         # no whole tile: ++accumulations over an empty parallel_for (Renderer.hpp:59-60,74-75), like the reference
+    r.Accumulate(3)
+    assert r.accumulations == 3 and r.accumulator().size == 0
     r.close()
     bad = mirt.scene.default9(); bad.geometry["material_ID"][3] = 99
     with pytest.raises(mirt.MirtError):
@@ -849,24 +849,50 @@ def test_accumulator_device_view_for_rccl(mirt):
     r.close()
 
 
-def test_bench_two_ranks_rehearsal(tmp_path):
-    """bench.py's torch.distributed path (env parsing, tile sharding, barriers, MAX/SUM reductions, gather) with two ranks
-    sharing this box's single GPU over gloo; on the 8-GPU node the driver runs the same code over RCCL."""
+def _bench_line(cmd, env, timeout):
     import json
     import subprocess
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, out.stdout[-500:]
+    return json.loads(line[0]), out.stderr
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's torch.distributed path (env parsing, tile sharding, barriers, MAX/SUM reductions, gather) with two ranks
+    sharing this box's single GPU over gloo; on the 8-GPU node the driver runs the same code over RCCL.  The N > 1 line carries what the
+    N = 1 line carries: a roofline for rank 0's share from the rocprofv3 --pmc child passes that rank 0 runs before it joins
+    the process group, the CPU baseline, and `group_host` — the library's own multi-GPU host run as a child over the same devices."""
+    import shutil
     import sys
     from conftest import ROOT
     env = dict(os.environ, MIRT_BENCH_SHARE_GPU="1", MIRT_BENCH_BACKEND="gloo")
     port = 29700 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "cfg2", "--spp", "5", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(line) == 1
-    d = json.loads(line[0])
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "cfg2", "--spp", "5"]
+    d, err = _bench_line(cmd, env, 900)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["image"] == "1024x1024" and d["gather_ms"] is not None
     assert d["value"] > 0 and d["roofline"]["bound"] == "valu" and d["roofline"]["hbm"]["frac"] > 0 and d["rays_per_step"] > 9e6
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["host_hardware_threads"] >= d["cpu_baseline"]["cores"]
+    assert "4 accumulations" in d["cpu_baseline"]["sample"] or int(d["cpu_baseline"]["sample"].split()[0]) >= 4
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        rf = d["roofline"]
+        assert rf["frac"] is not None and 0.0 < rf["frac"] == rf["useful_lane_frac"] <= rf["issue_frac"] <= 1.0, err[-1500:]
+        assert 0.0 < rf["arithmetic_frac"] < 1.0 and rf["traffic"] > 0 and rf["pmc"]["batch"] >= 5
+    gh = d["group_host"]
+    assert "error" not in gh, gh
+    assert gh["n_gpus"] == 2 and gh["value"] > 0 and gh["gather_ms"] is not None and gh["gather_ms"] > 0 and gh["devices"] == [0, 0]
+
+
+def test_bench_group_host_rehearsal():
+    """bench.py --group: one process, mirt_group_* over two members that share this box's GPU (slabs move by device copies; on distinct
+    devices the same call is the RCCL gather)."""
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MIRT_BENCH_DEVICES="0,0")
+    d, _ = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "cfg2", "--spp", "5"], env, 600)
+    assert d["n_gpus"] == 2 and d["devices"] == [0, 0] and d["value"] > 0 and d["gather_ms"] > 0 and d["rays_per_step"] > 9e6 and d["scaling"] == "strong"
 
 
 def test_cfg2_full_size_properties(mirt):
@@ -919,4 +945,123 @@ def test_edit_protocol_scene_and_camera_changes(mirt):
     o3 = ob.Oracle(sc, max_bounces=6, buckets=3, trav_mode=ob.TRAV_BRUTE); o3.Resize(64, 96); o3.Accumulate(6)
     assert_same(r.accumulator(), o3.accumulator(), "after bucket-count change"); assert r.Render()
     assert_same(r.GetFrame(), o3.Render(), "3-bucket median frame")
+    r.close()
+
+
+@pytest.mark.parametrize("name,n_tiles", [("cfg4", 8), ("cfg3", 10), ("cfg2", 10)])
+def test_bench_launch_shapes_vs_oracle(mirt, name, n_tiles):
+    """The launch shapes bench.py's driver line is produced with, against the brute-force oracle: cfg4 4096x4096 as ONE
+    batch of 32 accumulations (path ids slot << 24 | pixel with slots up to 31, 537 M-entry stream planes, the contribution-buffer path);
+    cfg3 1920x1088 as one batch of the 192 accumulations of three 64-accumulation steps issued with AccumulateAsync; cfg2 1024x1024 as one
+    batch of 256.  The oracle's cost is bounded by the number of tiles it renders (Oracle.Resize(w, h, tiles=...)), not by a smaller batch."""
+    cfg = mirt.scene.CONFIGS[name]
+    w, h, mb, buckets = cfg["width"], cfg["height"], cfg["max_bounces"], cfg["buckets"]
+    sc = mirt.scene.synthetic(cfg["n"], ambient=cfg["ambient"])
+    h_tiles, v_tiles = w // 16, h // 16
+    rng = np.random.default_rng(29)
+    tiles = np.unique(np.concatenate([[0, v_tiles * h_tiles - 1, (v_tiles // 2) * h_tiles + h_tiles // 2, (3 * v_tiles // 4) * h_tiles + h_tiles // 3],
+                                      rng.integers(0, h_tiles * v_tiles, n_tiles - 4)])).astype(np.uint32)
+    r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, use_bvh=True); r.Resize(w, h)
+    eff = r.get_policy()
+    if name == "cfg4":
+        assert eff["max_batch"] == 32 and eff["streams"] == 1          # the plan bench.py logs: 512 M primary rays per batch, one batch in flight
+        spp = 32
+        r.Accumulate(spp)
+    elif name == "cfg3":
+        assert eff["max_batch"] == 256 and eff["streams"] == 1
+        spp = 192
+        for _ in range(3):
+            r.AccumulateAsync(64)                                      # bench.py's timed region: three steps, launched as one batch at the synchronisation
+        r.Synchronize()
+    else:
+        assert eff["max_batch"] == 256
+        spp = 256
+        r.Accumulate(spp)
+    assert r.accumulations == spp
+    c = r.counters()
+    assert c["terminated"] + c["dropped"] == spp * h_tiles * v_tiles * 256
+    got = r.accumulator()[tiles]
+    r.close()
+    o = ob.Oracle(sc, max_bounces=mb, buckets=buckets, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h, tiles=tiles); o.Accumulate(spp)
+    assert_same(got, o.accumulator(), f"{name} at bench.py's launch shape ({spp} accumulations in one batch): {len(tiles)} tiles vs brute-force oracle")
+    assert got.any()
+
+
+def test_max_batch_at_its_documented_maximum(mirt):
+    """policy.max_batch is clamped to what path ids AND stream slots hold (mirt.h) instead of failing at the first launch.  Checked
+    where the clamp binds with little memory — a context that owns 2^22 pixels asks for 256 accumulations per batch and gets 255 — and, when
+    the device has the 200 GB free, on the whole 4096x4096 image with max_batch = 64 -> 63 (one Accumulate() call: the arena is carved for the limit)."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    r = mirt.Renderer(sc, max_bounces=2, use_bvh=True, max_batch=256); r.Resize(2048, 2048)
+    assert r.get_policy()["max_batch"] == 255
+    r.set_policy(max_batch=4)                                                  # (the arena of 255 x 2^22 rays is never allocated)
+    assert r.get_policy()["max_batch"] == 4
+    r.Accumulate(5)
+    o = ob.Oracle(sc, max_bounces=2, trav_mode=ob.TRAV_BRUTE); o.Resize(2048, 2048, tiles=np.array([5, 9000], dtype=np.uint32)); o.Accumulate(5)
+    assert_same(r.accumulator()[[5, 9000]], o.accumulator(), "2048x2048 after the clamp")
+    r.close()
+    import torch
+    free_b, _ = torch.cuda.mem_get_info(0)
+    r = mirt.Renderer(sc, max_bounces=2, use_bvh=True, max_batch=64); r.Resize(4096, 4096)
+    assert r.get_policy()["max_batch"] == 63
+    if free_b > 230 * (1 << 30):
+        r.Accumulate(1)
+        assert r.accumulations == 1 and r.counters()["terminated"] + r.counters()["dropped"] == 4096 * 4096
+    r.close()
+
+
+def test_policy_is_planned_before_the_first_launch(mirt):
+    """mirt_get_policy reports the batch plan launches will use (not a provisional 256) before anything was accumulated,
+    and a policy change the plan does not depend on keeps it."""
+    sc = mirt.scene.synthetic(1000, ambient=0.5)
+    r = mirt.Renderer(sc, max_bounces=3, use_bvh=True); r.Resize(1024, 1024)
+    before = r.get_policy()
+    r.Accumulate(2)
+    after = r.get_policy()
+    assert before["max_batch"] == after["max_batch"] == 256 and before["streams"] == after["streams"]
+    r.set_policy(trace_primary_rays=1)
+    assert r.get_policy()["max_batch"] == after["max_batch"]
+    r.close()
+
+
+def test_group_with_more_members_than_tile_rows(mirt):
+    """members beyond the last tile row own nothing; they count the Accumulate() calls and the group still renders the image."""
+    sc = mirt.scene.default9()
+    w, h, spp = 96, 32, 5                                                       # two tile rows, four members
+    o = ob.Oracle(sc, max_bounces=6, trav_mode=ob.TRAV_BRUTE); o.Resize(w, h); o.Accumulate(spp)
+    g = mirt.GroupRenderer(sc, devices=[0, 0, 0, 0], max_bounces=6, use_bvh=True); g.Resize(w, h); g.Accumulate(spp)
+    assert g.accumulations == spp
+    assert_same(g.accumulator(), o.accumulator(), "group of 4 on 2 tile rows")
+    assert g.Render(); assert_same(g.GetFrame(), o.Render(), "its frame")
+    g.close()
+
+
+@pytest.mark.parametrize("n", [16384, 40000])
+def test_wide_records_with_a_stack_deeper_than_lds(mirt, n):
+    """the spill path of node_step_wide (kernels.hpp: up to three pushes per 4-wide level past the 16 u16 / 12 u32 stack entries kept in
+    LDS).  n overlapping spheres on a line: a ray along the line meets all four child boxes of every 4-wide node on its way down, so the stack grows
+    by three per level — 7 levels (n = 16384, u16 entries) and 8 levels (n = 40000, u32 entries) pass the LDS-resident part.  Rays along the line,
+    against it and oblique ones, closest-hit and any-hit, vs the oracle's brute-force loops."""
+    sc = mirt.scene.synthetic(n, ambient=0.5)
+    length = 240.0                                                               # |x| <= 120: binary16 planes are precise enough for radius 0.5, so the 4-wide records are used
+    sc.geometry["position"] = np.stack([np.linspace(-0.5 * length, 0.5 * length, n), np.zeros(n), np.zeros(n)], axis=1).astype(np.float32)
+    sc.geometry["radius_sq"] = np.float32(0.25)
+    r = mirt.Renderer(sc, max_bounces=3, use_bvh=True)
+    info = r.debug_info()
+    assert info["wide"] == 1 and info["depth"] >= (14 if n == 16384 else 16)
+    rng = np.random.default_rng(3)
+    m = 3000
+    px = np.concatenate([np.full(m // 3, -0.5 * length - 3.0), np.full(m // 3, 0.5 * length + 3.0), rng.uniform(-0.5 * length - 2.0, 0.5 * length + 2.0, m - 2 * (m // 3))]).astype(np.float32)
+    p = np.stack([px, rng.uniform(-0.3, 0.3, m), rng.uniform(-0.3, 0.3, m)]).astype(np.float32)
+    d = np.stack([np.concatenate([np.ones(m // 3), -np.ones(m // 3), rng.uniform(-1, 1, m - 2 * (m // 3))]), rng.normal(0, 0.02, m), rng.normal(0, 0.02, m)])
+    d[:, 2 * (m // 3):] += rng.normal(0, 0.5, (3, m - 2 * (m // 3)))
+    d = (d / np.linalg.norm(d, axis=0)).astype(np.float32)
+    # start the axis-parallel rays inside the row as well: every box on the way is entered before any sphere in front prunes it
+    p[0, : m // 6] = rng.uniform(-0.5 * length, 0.5 * length, m // 6).astype(np.float32)
+    o = ob.Oracle(sc, max_bounces=3, trav_mode=ob.TRAV_BRUTE)
+    tg, ig = r.debug_trace_closest(p, d)
+    to, io = o.trace_closest(p, d, ob.TRAV_BRUTE)
+    assert np.array_equal(ig, io) and np.array_equal(tg.view(np.uint32), to.view(np.uint32))
+    tfar = rng.uniform(0.01, 5.0, m).astype(np.float32)
+    assert np.array_equal(r.debug_trace_shadow(p, d, tfar), o.trace_shadow(p, d, tfar, ob.TRAV_BRUTE))
     r.close()
