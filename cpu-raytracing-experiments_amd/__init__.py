@@ -16,6 +16,7 @@ import subprocess
 import numpy as np
 
 from . import distributed as distributed  # noqa: F401
+from . import hdr as hdr  # noqa: F401
 from . import scene as scene  # noqa: F401  (re-export)
 from .scene import MATERIAL, NODE, SPHERE, Camera, Scene
 

@@ -1,13 +1,16 @@
 // mirt_headless.cpp — headless stand-in for RaytracingApp (Application.cpp:32-235, 361-386): builds a scene the way
 // the reference's constructor does, then drives the renderer with the reference's call protocol
-// (Resize -> [Accumulate, Render] per frame) through mirt_host.hpp, and writes the resolved frame as a PFM
-// (the reference's F5 screenshot is stbi_write_hdr of the same RGBA buffer, flipped vertically: Image.cpp:71-74).
+// (Resize -> [Accumulate, Render] per frame) through mirt_host.hpp, and writes the resolved frame in the reference's own screenshot
+// format — Radiance .hdr, flipped vertically like Image::Store (Image.cpp:71-74) — or as a PFM (by the extension of --out).  --hdri loads the
+// environment map the way the constructor does (stbi_loadf(..., 4), Application.cpp:225-231); --ambient sets sky.ambient_color, which scales it.
 //
-//   mirt_headless --scene default9|furnace|bvh_test|synthetic:N [--size WxH] [--spp N | --frames N] [--bounces B] [--buckets K] [--brute] [--devices 0,1,..] [--out f.pfm]
+//   mirt_headless --scene default9|furnace|bvh_test|synthetic:N [--size WxH] [--spp N | --frames N] [--bounces B] [--buckets K] [--brute] [--devices 0,1,..]
+//                 [--hdri env.hdr] [--ambient A] [--out frame.hdr|frame.pfm]
 // --devices: the GPUs the one Renderer object uses (tile rows split over them inside the library, one RCCL gather per frame read).
 // --frames N is the UI loop itself (Application.cpp:373-380): N frames of { Accumulate(); Render(); }; the report lists the frames on
 // which Render() produced output (every `buckets`-th, Renderer.hpp:437) and a hash of the last frame shown.
 #include "mirt_host.hpp"
+#include "hdr_io.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -113,11 +116,22 @@ static bool write_pfm(const std::string& path, const std::vector<float>& rgba, u
 }
 
 int main(int argc, char** argv) {
-	std::string scene_name = "default9", out;
+	std::string scene_name = "default9", out, hdri;
 	uint32_t w = 512, h = 512, spp = 10, n = 0;
 	RendererPolicy policy;
 	float ambient = 0.0f;
+	bool ambient_set = false;
 	std::vector<int> devices = { 0 };
+	if (argc == 4 && std::string(argv[1]) == "--convert-hdr") {
+		// file-format check without a GPU: read a picture like stbi_loadf does (top-down) and store it again like Image::Store does (which
+		// flips, so the rows are handed over bottom-up): the output decodes to the same texels
+		std::vector<float> texels; int32_t iw = 0, ih = 0;
+		const std::string why = mirt_hdr::read(argv[2], texels, iw, ih);
+		if (!why.empty()) { std::fprintf(stderr, "mirt_headless: %s: %s\n", argv[2], why.c_str()); return 1; }
+		std::vector<float> flipped(texels.size());
+		for (int32_t y = 0; y < ih; y++) std::memcpy(&flipped[static_cast<size_t>(y) * iw * 4], &texels[static_cast<size_t>(ih - 1 - y) * iw * 4], static_cast<size_t>(iw) * 16);
+		return mirt_hdr::write_flipped(argv[3], flipped.data(), static_cast<uint32_t>(iw), static_cast<uint32_t>(ih)) ? 0 : 1;
+	}
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
 		auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -126,7 +140,8 @@ int main(int argc, char** argv) {
 		else if (a == "--spp" || a == "--frames") spp = static_cast<uint32_t>(std::atoi(next()));
 		else if (a == "--bounces") policy.max_bounces = static_cast<uint32_t>(std::atoi(next()));
 		else if (a == "--buckets") policy.buckets = static_cast<uint32_t>(std::atoi(next()));
-		else if (a == "--ambient") ambient = static_cast<float>(std::atof(next()));
+		else if (a == "--ambient") { ambient = static_cast<float>(std::atof(next())); ambient_set = true; }
+		else if (a == "--hdri") hdri = next();
 		else if (a == "--brute") policy.use_bvh = false;
 		else if (a == "--out") out = next();
 		else if (a == "--devices") { devices.clear(); for (const char* p = next(); *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } if (devices.empty()) return 2; }
@@ -139,6 +154,11 @@ int main(int argc, char** argv) {
 		else if (scene_name == "bvh_test") scene_bvh_test(scene);
 		else if (scene_name.rfind("synthetic:", 0) == 0) { n = static_cast<uint32_t>(std::atoi(scene_name.c_str() + 10)); if (n < 2) return 2; scene_synthetic(scene, n, ambient); }
 		else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
+		if (ambient_set) scene.sky.ambient_color[0] = scene.sky.ambient_color[1] = scene.sky.ambient_color[2] = ambient;
+		if (!hdri.empty()) {                                           // Application.cpp:225-231
+			const std::string why = mirt_hdr::read(hdri, scene.sky.hdri_data, scene.sky.hdri_width, scene.sky.hdri_height);
+			if (!why.empty()) { std::fprintf(stderr, "mirt_headless: %s: %s\n", hdri.c_str(), why.c_str()); return 1; }
+		}
 		scene.RebuildAcceleration();                                   // Application.cpp:233-234
 
 		Renderer renderer{ scene, policy, devices };
@@ -170,7 +190,11 @@ int main(int argc, char** argv) {
 		            scene_name.c_str(), scene.geometry.size(), scene.acceleration_structure.nodes.size(), scene.lighting_acceleration.prims.size(), w, h,
 		            renderer.accumulations(), (unsigned long long)c.rays, (unsigned long long)c.shadow_rays, (unsigned long long)c.terminated,
 		            (unsigned long long)c.dropped, sec, c.rays / sec / 1e6, (unsigned long long)hsh, have_frame ? "true" : "false", frames_due.c_str(), (unsigned long long)frame_hsh, devices.size(), renderer.gather_ms());
-		if (!out.empty() && have_frame && !write_pfm(out, renderer.GetFrame(), w, h)) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+		if (!out.empty() && have_frame) {
+			const bool as_hdr = out.size() >= 4 && out.compare(out.size() - 4, 4, ".hdr") == 0;
+			const bool ok = as_hdr ? mirt_hdr::write_flipped(out, renderer.GetFrame().data(), w, h) : write_pfm(out, renderer.GetFrame(), w, h);
+			if (!ok) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+		}
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "mirt_headless: %s\n", e.what());
 		return 1;

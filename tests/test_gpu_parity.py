@@ -1065,3 +1065,30 @@ def test_wide_records_with_a_stack_deeper_than_lds(mirt, n):
     tfar = rng.uniform(0.01, 5.0, m).astype(np.float32)
     assert np.array_equal(r.debug_trace_shadow(p, d, tfar), o.trace_shadow(p, d, tfar, ob.TRAV_BRUTE))
     r.close()
+
+
+def test_cpp_host_reads_and_writes_radiance_hdr(mirt, tmp_path):
+    """mirt_headless --hdri env.hdr --out frame.hdr: the reference's own file formats at both ends of the harness (Application.cpp:225-231
+    environment map, Image.cpp:71-74 flipped screenshot).  The environment is written by the Python host, decoded by the C++ one; the sky
+    lookups of the render must equal the oracle's on the same decoded texels (accumulator bit for bit), and the stored frame, read back by
+    Python, must be the RGBE quantisation of the oracle's frame."""
+    import json
+    import subprocess
+    exe = os.path.join(mirt.CSRC, "mirt_headless")
+    rng = np.random.default_rng(77)
+    env = (rng.uniform(0.0, 1.0, (24, 48, 4)) ** 3 * 6.0).astype(np.float32)
+    env_path, out_path = str(tmp_path / "env.hdr"), str(tmp_path / "frame.hdr")
+    mirt.hdr.write_hdr(env_path, env[::-1])                                  # (write_hdr flips: hand the rows over bottom-up so that the file's top row is env[0])
+    sc = mirt.scene.default9()
+    sc.hdri = mirt.hdr.read_hdr(env_path)
+    assert sc.hdri.shape == (24, 48, 4) and np.array_equal(sc.hdri.view(np.uint32), mirt.hdr.rgbe_to_float(mirt.hdr.float_to_rgbe(env)).view(np.uint32))
+    sc.ambient = np.array([0.8, 0.8, 0.8], dtype=np.float32)
+    o = ob.Oracle(sc, max_bounces=16, trav_mode=ob.TRAV_BRUTE); o.Resize(96, 64); o.Accumulate(10)
+    rep = json.loads(subprocess.run([exe, "--scene", "default9", "--size", "96x64", "--spp", "10", "--hdri", env_path, "--ambient", "0.8", "--out", out_path],
+                                    check=True, capture_output=True, text=True).stdout)
+    assert rep["accumulator_fnv1a"] == _fnv1a(o.accumulator()) and rep["frame_ready"]
+    frame = o.Render()
+    assert frame[..., :3].max() > 0.05
+    got = mirt.hdr.read_hdr(out_path)                                       # top-down
+    want = mirt.hdr.rgbe_to_float(mirt.hdr.float_to_rgbe(frame))[::-1]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

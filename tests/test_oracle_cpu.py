@@ -329,3 +329,36 @@ def test_host_code_under_sanitizers(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "n=20000 nodes=39999 recs=19999" in out.stdout
+
+
+def test_radiance_hdr_files_round_trip_between_the_two_hosts(mirt, tmp_path):
+    """The reference's two uses of Radiance RGBE pictures (stb_image / stb_image_write, not vendored: their published arithmetic restated):
+    the environment map `stbi_loadf(..., 4)` (Application.cpp:225-231) and the flipped screenshot `stbi_write_hdr` (Image.cpp:71-74).
+    Python (hdr.py, flat scanlines) and C++ (csrc/hdr_io.hpp through `mirt_headless --convert-hdr`, run-length scanlines) must read each
+    other's files to the same texels, and those are the RGBE quantisation of what was written: 8-bit mantissas under the largest channel's
+    exponent, truncated."""
+    import subprocess
+    hdr = mirt.hdr
+    exe = os.path.join(mirt.CSRC, "mirt_headless")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", mirt.CSRC, "mirt_headless"], check=True)
+    rng = np.random.default_rng(5)
+    for h, w in ((7, 5), (16, 40), (3, 300)):
+        img = (rng.uniform(0.0, 1.0, (h, w, 4)) ** 4 * 50.0).astype(np.float32)
+        img[0, 0, :3] = 0.0; img[-1, -1, :3] = [1e-40, 0.0, 0.0]                  # exponent byte 0
+        img[1, :, :3] = 0.25                                                     # a long run for the run-length form
+        # known answers of the arithmetic
+        q = hdr.float_to_rgbe(img)
+        assert tuple(q[0, 0]) == (0, 0, 0, 0) and tuple(q[-1, -1]) == (0, 0, 0, 0) and tuple(q[1, 0]) == (128, 128, 128, 127)
+        want = hdr.rgbe_to_float(q)                                              # what any reader must return: bottom-up like the frame handed to write_hdr
+        assert np.all(want[..., 3] == 1.0) and np.all(want[..., :3] <= img[..., :3]) and np.all(img[..., :3] - want[..., :3] <= img[..., :3].max(-1, keepdims=True) / 128.0 + 1e-30)
+        a, b = str(tmp_path / "py.hdr"), str(tmp_path / "cpp.hdr")
+        hdr.write_hdr(a, img)                                                    # Image::Store: flips
+        top_down = hdr.read_hdr(a)                                               # stbi_loadf: no flip
+        assert np.array_equal(top_down.view(np.uint32), want[::-1].view(np.uint32))
+        subprocess.run([exe, "--convert-hdr", a, b], check=True)                 # C++ read + flip + Image::Store
+        raw = open(b, "rb").read()
+        assert raw.startswith(b"#?RADIANCE\n") and b"FORMAT=32-bit_rle_rgbe\n" in raw and (b"-Y %d +X %d\n" % (h, w)) in raw
+        if 8 <= w < 32768:
+            assert len(raw) < len(open(a, "rb").read()) + 200 and raw[raw.index(b"+X %d\n" % w) + len(b"+X %d\n" % w):][:2] == b"\x02\x02"   # run-length scanlines
+        assert np.array_equal(hdr.read_hdr(b).view(np.uint32), top_down.view(np.uint32))
