@@ -99,6 +99,7 @@ struct FrameParams {
 	uint32_t buckets;
 	uint32_t mis;               // MIS && light_count > 0 (Q12 guard)
 	uint32_t n_lights;
+	uint32_t first_groups;      // k_shade<FIRST>: a chunk of 512 pixels x the batch's accumulations is handed out in this many pieces (small images: enough pieces for an even load)
 	float inv_n_pix, inv_h_tiles, inv_run_tiles;   // 1/n_pix, 1/h_tiles, 1/run_tiles for udiv_f (no integer division in the kernels)
 };
 struct DevCounters {
@@ -883,9 +884,16 @@ MIRT_DI void shadow_finish(const ShadowBuf& sh, const ShadowSink& sink, uint32_t
 // Either count pointer may refer to a zero word (first bounce: no shadow rays yet; after the last extension: shadow only).
 // 8 waves/SIMD (= two 16-wave workgroups per CU, the LDS plan of the binary16 layout) caps the kernel at 64 VGPRs.
 // PRIMARY != 0 = bounce 0: the rays are generated from their index (primary_ray), nothing is read; no shadow rays are pending.
-//   kPrimaryAll: every ray i of the batch, numbered 0 .. n_pix * batch_n - 1;  kPrimaryList: the rays whose index k_primary_hits
-//   listed in in.path (pixels without a candidate list), closest_queue = that list; results are stored under the ray's index.
+//   kPrimaryAll: every ray i of the batch, numbered 0 .. n_pix * batch_n - 1;  kPrimaryList: every sample of the pixels k_primary_cand
+//   listed in in.path (pixels without a candidate list; closest_queue.n[0] = how many); results are stored under the ray's index.
 constexpr int kPrimaryNone = 0, kPrimaryAll = 1, kPrimaryList = 2;
+// kPrimaryList numbering: ray j of n_ov * batch_n is sample slot j / n_ov of the j % n_ov-th listed pixel (slot-major: the lanes of a wave
+// take neighbouring pixels of one accumulation, like everywhere else); returns its index in the batch, slot * n_pix + pixel.
+MIRT_DI uint32_t primary_list_ray(const FrameParams& fp, const uint32_t* __restrict__ ov_pix, uint32_t n_ov, float inv_n_ov, uint32_t j) {
+	uint32_t k;
+	const uint32_t slot = udiv_f(j, n_ov, inv_n_ov, k);
+	return slot * fp.n_pix + ov_pix[k];
+}
 template <bool COUNT, int PRIMARY>
 __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FrameParams fp,
                                                        StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
@@ -894,8 +902,10 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
                                                        Queue shadow_queue, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
                                                        DevCounters* ctr) {
 	extern __shared__ float4 lds[];
-	if (PRIMARY == kPrimaryAll) closest_queue.n = nullptr;                     // identity numbering: ray i is slot i
-	const uint32_t nc = PRIMARY == kPrimaryAll ? fp.n_pix * fp.batch_n : queue_total(closest_queue), ns = PRIMARY ? 0u : queue_total(shadow_queue);
+	const uint32_t n_ov = PRIMARY == kPrimaryList ? closest_queue.n[0] : 0u;     // listed pixels (k_primary_cand)
+	const float inv_n_ov = 1.0f / static_cast<float>(n_ov ? n_ov : 1u);
+	if (PRIMARY) closest_queue.n = nullptr;                                    // identity numbering: ray j is slot j
+	const uint32_t nc = PRIMARY == kPrimaryAll ? fp.n_pix * fp.batch_n : PRIMARY == kPrimaryList ? n_ov * fp.batch_n : queue_total(closest_queue), ns = PRIMARY ? 0u : queue_total(shadow_queue);
 	if (nc + ns == 0) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		if (nc && PRIMARY != kPrimaryList) atomicAdd(&ctr->rays, static_cast<unsigned long long>(nc));     // (k_primary_hits has counted the whole batch)
@@ -907,11 +917,11 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 		const TraceLds tl = stage_bvh(sc, lds);
 		{
 			auto load_ray = [&](uint32_t i, float& px, float& py, float& pz, float& dx, float& dy, float& dz, float& tf) {
-				if (PRIMARY) { uint32_t path; primary_ray(fp, PRIMARY == kPrimaryList ? in.path[i] : i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
+				if (PRIMARY) { uint32_t path; primary_ray(fp, PRIMARY == kPrimaryList ? primary_list_ray(fp, in.path, n_ov, inv_n_ov, i) : i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
 				else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
 				tf = MIRT_FLT_MAX;                                                 // hit reset, Renderer.hpp:150-158
 			};
-			auto store_result = [&](uint32_t i, const Trav& t, bool) { const uint32_t o = PRIMARY == kPrimaryList ? in.path[i] : i; tfar_out[o] = t.tfar; prim_out[o] = t.prim; };
+			auto store_result = [&](uint32_t i, const Trav& t, bool) { const uint32_t o = PRIMARY == kPrimaryList ? primary_list_ray(fp, in.path, n_ov, inv_n_ov, i) : i; tfar_out[o] = t.tfar; prim_out[o] = t.prim; };
 			trace_queue<kClosest, COUNT>(sc, tl, closest_queue, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
 		if (!PRIMARY) {
@@ -923,7 +933,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 		}
 	} else {
 		// brute force over all prims (the reference as shipped); also the no-spheres case
-		const QueueView qc = PRIMARY == kPrimaryAll ? queue_identity(nc) : queue_view(closest_queue);      // (kPrimaryList is never launched without a tree)
+		const QueueView qc = PRIMARY ? queue_identity(nc) : queue_view(closest_queue);      // (kPrimaryList is never launched without a tree)
 		const QueueView qs = PRIMARY ? queue_identity(0u) : queue_view(shadow_queue);
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < nc; base += gridDim.x * kTraceBlock) {
 			const bool active = base + threadIdx.x < nc;
@@ -958,13 +968,15 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 // for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
 template <bool COUNT, int PRIMARY>
 __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
-                                                    ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr) {
+                                                    ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr, const uint32_t* ov_count) {
 	__shared__ float s_t[16];
 	__shared__ int32_t s_p[16];
 	const uint32_t nc = min(*fat_closest.count, fat_closest.capacity), ns = min(*fat_shadow.count, fat_shadow.capacity);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+	const uint32_t n_ov = PRIMARY == kPrimaryList ? *ov_count : 0u;
+	const float inv_n_ov = 1.0f / static_cast<float>(n_ov ? n_ov : 1u);
 	for (uint32_t k = blockIdx.x; k < nc; k += gridDim.x) {
-		const uint32_t i = PRIMARY == kPrimaryList ? in.path[fat_closest.rays[k]] : fat_closest.rays[k];
+		const uint32_t i = PRIMARY == kPrimaryList ? primary_list_ray(fp, in.path, n_ov, inv_n_ov, fat_closest.rays[k]) : fat_closest.rays[k];
 		float px, py, pz, dx, dy, dz;
 		if (PRIMARY) { uint32_t path; primary_ray(fp, i, path, dx, dy, dz); px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; }
 		else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
@@ -1013,7 +1025,8 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp,
 // 0.7072 / |projection.z| + margins — the jitter moves a sample by at most half a pixel per axis in the image plane, whose
 // points are at least |z| from the eye).  Same persistent-wave traversal as k_trace; the result is the pixel's candidate list.
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, FrameParams fp, uint32_t* __restrict__ cand, float rho, uint32_t* work, FatList unused, DevCounters* ctr) {
+__global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, FrameParams fp, uint32_t* __restrict__ cand, float rho, uint32_t* work, FatList unused, DevCounters* ctr,
+                                                                uint32_t* __restrict__ ov_pix, uint32_t* __restrict__ ov_count) {
 	extern __shared__ float4 lds[];
 	const uint32_t n = fp.n_pix;
 	if (n == 0 || static_cast<uint64_t>(blockIdx.x) * 64u >= n) return;
@@ -1026,51 +1039,62 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, Fr
 		px = fp.cam.pos[0]; py = fp.cam.pos[1]; pz = fp.cam.pos[2]; dx = d.x; dy = d.y; dz = d.z; tf = MIRT_FLT_MAX;
 	};
 	auto store_result = [&](uint32_t pix, const Trav& t, bool) {
-		cand[pix] = static_cast<uint32_t>(t.prim) > kCandMax ? kCandOverflow : static_cast<uint32_t>(t.prim);
+		const bool over = static_cast<uint32_t>(t.prim) > kCandMax;
+		cand[pix] = over ? kCandOverflow : static_cast<uint32_t>(t.prim);
+		// pixels without a list: every sample is traced by k_trace<kPrimaryList>.  One atomic per wave and flush for the lanes that report one.
+		const unsigned long long m = __ballot(over);
+		if (over) {
+			const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
+			uint32_t first = 0;
+			if (lane_id() == leader) first = atomicAdd(ov_count, static_cast<uint32_t>(__popcll(m)));
+			first = __builtin_amdgcn_readlane(first, leader);
+			if (ov_pix) ov_pix[first + mask_rank(m)] = pix;
+		}
 	};
 	trace_queue<kCollect, COUNT>(sc, tl, Queue{ nullptr, 0u }, n, work, unused, c_nodes, c_spheres, load_ray, store_result, Collect{ cand, rho, n });
 	if (COUNT) { wave_sum(c_nodes, &ctr->nodes); wave_sum(c_spheres, &ctr->spheres); }
 }
-// Traverse (BVH.hpp:309-360) for the primary rays of a batch, given the lists: each ray is intersected with its pixel's candidates
-// by the reference's own arithmetic (sphere_closest_tie: the (dist, prim index) minimum does not depend on the order of the list);
-// rays of pixels without a list are compacted into `fallback` (their indices in fallback_idx) for k_trace<kPrimaryList>.
+// Traverse (BVH.hpp:309-360) for the camera rays of a batch, given the lists: one lane per PIXEL runs the batch's accumulations over it.  What
+// depends on the pixel alone — tile, x, y, seed[ID], the list and its first kCandRegs spheres — is set up once, so a sample costs its ray
+// (hash_2d, two PCG draws, the quaternion rotation and normalisation of Camera::generate_ray, Camera.hpp:80-88) + the exact sphere tests on
+// registers (sphere_closest_tie: the reference's arithmetic; the (dist, prim index) minimum does not depend on the order of the list) + one 8-B
+// hit record, written for 64 neighbouring pixels at a time.  (Round 2 ran one lane per SAMPLE: every ray paid the pixel's set-up and walked the
+// list through three dependent loads — 7.3 ms per cfg4 batch of 537 M rays.)  Pixels without a list are skipped: k_trace<kPrimaryList> traces
+// all their samples.
+constexpr uint32_t kCandRegs = 3;
 template <bool COUNT>
-__global__ __launch_bounds__(kShadeBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint32_t* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
-                                                              uint32_t* __restrict__ fallback_idx, Queue fallback, DevCounters* ctr) {
-	const uint32_t total = fp.n_pix * fp.batch_n;
-	if (blockIdx.x == 0 && threadIdx.x == 0 && total) atomicAdd(&ctr->rays, static_cast<unsigned long long>(total));
+__global__ __launch_bounds__(kBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint32_t* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, DevCounters* ctr) {
+	if (blockIdx.x == 0 && threadIdx.x == 0 && fp.n_pix) atomicAdd(&ctr->rays, static_cast<unsigned long long>(fp.n_pix) * fp.batch_n);     // Renderer.hpp:165: every camera ray of the batch
 	uint32_t c_spheres = 0;
-	for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
-		const uint32_t i = base + threadIdx.x;
-		bool fall_back = false;
-		if (i < total) {
-			uint32_t path; float dx, dy, dz;
-			primary_ray(fp, i, path, dx, dy, dz);
-			const uint32_t pix = path & fp.pix_mask;
-			const uint32_t cnt = cand[pix];
-			if (cnt == kCandOverflow) fall_back = true;
-			else {
-				float tfar = MIRT_FLT_MAX; int32_t prim = -1;                      // hit reset, Renderer.hpp:150-158
-				for (uint32_t k = 0; k < kCandMax; k++) {
-					if (__ballot(k < cnt) == 0ull) break;                          // wave-uniform exit: most lists hold one to three spheres
-					if (k < cnt) {
-						const uint32_t id = cand[static_cast<size_t>(k + 1u) * fp.n_pix + pix];
-						sphere_closest_tie(sc.spheres[id], static_cast<int32_t>(id), fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2], dx, dy, dz, tfar, prim);
-						if (COUNT) c_spheres++;
-					}
-				}
-				tfar_out[i] = tfar; prim_out[i] = prim;
-			}
+	const float ox = fp.cam.pos[0], oy = fp.cam.pos[1], oz = fp.cam.pos[2];
+	for (uint32_t pix = blockIdx.x * kBlock + threadIdx.x; pix < fp.n_pix; pix += gridDim.x * kBlock) {
+		const uint32_t cnt = cand[pix];
+		if (cnt == kCandOverflow) continue;
+		uint32_t tile; int32_t x, y;
+		pixel_xy(fp, pix, tile, x, y);
+		const uint32_t seed = (tile * kTileSize + (pix & 255u)) * (fp.max_bounces * 2u + 1u);      // seed[ID], Renderer.hpp:107
+		float4 s[kCandRegs]; int32_t id[kCandRegs];
+		for (uint32_t k = 0; k < kCandRegs; k++) {
+			id[k] = k < cnt ? static_cast<int32_t>(cand[static_cast<size_t>(k + 1u) * fp.n_pix + pix]) : -1;
+			s[k] = sc.spheres[id[k] < 0 ? 0 : id[k]];
 		}
-		// rays without a list (a few per cent, clustered) are appended per WAVE, one atomic for the waves that have any: no workgroup
-		// barrier in this kernel.  All waves of a block-iteration use its segment, so the segment capacity argument of k_shade holds.
-		const unsigned long long m = __ballot(fall_back);
-		if (m != 0ull) {
-			const uint32_t seg = (base / kShadeBlock) % kSegs;
-			uint32_t first = 0;
-			if (lane_id() == 0) first = atomicAdd(fallback.n + seg * kSegPitch, static_cast<uint32_t>(__popcll(m)));
-			first = __builtin_amdgcn_readfirstlane(first);
-			if (fall_back) fallback_idx[seg * fallback.seg_cap + first + mask_rank(m)] = i;
+		for (uint32_t slot = 0; slot < fp.batch_n; slot++) {
+			uint32_t rng = hash_2d(fp.acc_base + slot + 1u, seed);                 // ++accumulations, Renderer.hpp:74,117
+			const float s0 = rand_unit_float(rng);
+			const float s1 = rand_unit_float(rng);
+			const f3 d = camera_ray_dir(fp.cam, x, y, s0, s1);
+			float tfar = MIRT_FLT_MAX; int32_t prim = -1;                          // hit reset, Renderer.hpp:150-158
+			for (uint32_t k = 0; k < kCandRegs; k++) if (id[k] >= 0) sphere_closest_tie(s[k], id[k], ox, oy, oz, d.x, d.y, d.z, tfar, prim);
+			for (uint32_t k = kCandRegs; k < kCandMax; k++) {                      // the rest of a long list, from L1
+				if (__ballot(k < cnt) == 0ull) break;
+				if (k < cnt) {
+					const uint32_t j = cand[static_cast<size_t>(k + 1u) * fp.n_pix + pix];
+					sphere_closest_tie(sc.spheres[j], static_cast<int32_t>(j), ox, oy, oz, d.x, d.y, d.z, tfar, prim);
+				}
+			}
+			if (COUNT) c_spheres += cnt;
+			const size_t i = static_cast<size_t>(slot) * fp.n_pix + pix;
+			tfar_out[i] = tfar; prim_out[i] = prim;
 		}
 	}
 	if (COUNT) wave_sum(c_spheres, &ctr->spheres);
@@ -1105,12 +1129,19 @@ MIRT_DI uint32_t block_compact(bool flag, uint32_t value, uint32_t* scratch, uin
 	return total;
 }
 
+// Block-iterations.  A later bounce reads a stream: iteration t covers its ray numbers [512 t, 512 t + 512), t = blockIdx.x, + gridDim.x, ...
+// Bounce 0 (FIRST) has no stream — ray i = slot * n_pix + pixel is a function of its index — and runs PIXEL-MAJOR: a workgroup takes chunks of
+// 512 local pixels (two tiles) and runs all the batch's accumulations over each, so what depends on the pixel alone (tile, x, y, seed[ID],
+// seed[ID]) is set up once per chunk.  Its hit records come from k_primary_hits (pixels with a candidate list) or k_trace.
+// (Measured and dropped twice: the candidate tests inside this kernel instead of k_primary_hits — ray-major in round 2, pixel-major in
+// round 3: at 6 waves per SIMD and 80 VGPRs the list's dependent loads cost k_shade<FIRST> 5 ms per cfg4 batch, as much as the kernel saved.)
 template <bool FIRST>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
+__global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
                                                   const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
                                                   Queue in_queue, Queue next_queue, Queue shadow_queue, float* __restrict__ accum, DevCounters* ctr) {
 	const QueueView qin = FIRST ? queue_identity(fp.n_pix * fp.batch_n) : queue_view(in_queue);
 	const uint32_t n = qin.pre[kSegs];
+	const uint32_t n_chunks = (fp.n_pix + kShadeBlock - 1u) / kShadeBlock;      // FIRST
 	const bool last_bounce = !(bounce < fp.max_bounces - 1u);                 // Renderer.hpp:358
 	const float light_selection_pdf = 1.0f / static_cast<float>(fp.n_lights);  // Renderer.hpp:78
 	__shared__ uint32_t append_scratch[72];
@@ -1118,35 +1149,75 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 	__shared__ uint32_t hit_list[kShadeBlock];
 	__shared__ float4 s_albedo[MIRT_MAX_MATERIALS + 1], s_emission[MIRT_MAX_MATERIALS + 1];      // scene.material: 2 KB, read by every hit
 	uint32_t c_term = 0, c_drop = 0, parity = 0;
-	if (blockIdx.x * kShadeBlock >= n) return;
+	const uint32_t n_units = n_chunks * fp.first_groups;                       // FIRST: pieces of work = (chunk, group of accumulations)
+	if (FIRST ? blockIdx.x >= n_units : blockIdx.x * kShadeBlock >= n) return;
 	for (uint32_t m = threadIdx.x; m < sc.n_mat; m += kShadeBlock) { s_albedo[m] = sc.mat_albedo[m]; s_emission[m] = sc.mat_emission[m]; }
 	__syncthreads();            // the table is read by every wave in phase 2; k_shade<FIRST> reaches no other barrier before that (the early return above is block-uniform)
 
-	// this lane's ray of the stream for the block-iteration at hand, and its hit record: requested one iteration ahead, so that the
+	// !FIRST: this lane's ray of the stream for the block-iteration at hand, and its hit record: requested one iteration ahead, so that the
 	// first of the iteration's three dependent memory round trips is already under way
-	uint32_t next_slot = (blockIdx.x * kShadeBlock + threadIdx.x < n) ? queue_slot(qin, blockIdx.x * kShadeBlock, blockIdx.x * kShadeBlock + threadIdx.x) : 0u;
-	int32_t next_prim = prim_in[next_slot];
-	for (uint32_t base = blockIdx.x * kShadeBlock; base < n; base += gridDim.x * kShadeBlock, parity ^= 1u) {
+	uint32_t next_slot = 0u; int32_t next_prim = -1;
+	if (!FIRST) {
+		next_slot = (blockIdx.x * kShadeBlock + threadIdx.x < n) ? queue_slot(qin, blockIdx.x * kShadeBlock, blockIdx.x * kShadeBlock + threadIdx.x) : 0u;
+		next_prim = prim_in[next_slot];
+	}
+	// FIRST: the pixel of this lane in the chunk at hand, and what depends on it alone
+	uint32_t unit = blockIdx.x, chunk = 0u, slot_it = 0u, slot_end = 0u, pix = 0u, pix_seed = 0u;
+	int32_t pix_x = 0, pix_y = 0;
+	for (uint32_t base = blockIdx.x * kShadeBlock; FIRST ? unit < n_units : base < n; parity ^= 1u) {
+		const bool new_unit = FIRST && slot_it == slot_end;                    // wave-uniform
+		if (new_unit) {
+			chunk = unit / fp.first_groups;
+			const uint32_t g = unit - chunk * fp.first_groups;
+			slot_it = g * fp.batch_n / fp.first_groups; slot_end = (g + 1u) * fp.batch_n / fp.first_groups;
+		}
+		const uint32_t iteration = FIRST ? chunk * fp.batch_n + slot_it : base / kShadeBlock;     // FIRST: every (chunk, slot) exactly once
 		// ---- phase 1, one lane per ray of the stream: misses end here; hits are only listed ----
 		bool is_hit = false;
-		const uint32_t my_slot = next_slot;
-		const int32_t my_prim = next_prim;
-		{
+		uint32_t my_slot = next_slot;
+		int32_t my_prim = next_prim;
+		float my_tfar = 0.0f;
+		f3 my_D{0, 0, 0};
+		uint32_t my_path = 0u;
+		bool lane_on;
+		if (FIRST) {
+			if (new_unit) {                                                      // a new chunk of pixels
+				pix = chunk * kShadeBlock + threadIdx.x;
+				if (pix < fp.n_pix) {
+					uint32_t tile;
+					pixel_xy(fp, pix, tile, pix_x, pix_y);
+					pix_seed = (tile * kTileSize + (pix & 255u)) * (fp.max_bounces * 2u + 1u);      // seed[ID], Renderer.hpp:107
+				}
+			}
+			lane_on = pix < fp.n_pix;
+			my_slot = slot_it * fp.n_pix + pix;                                 // the ray's index in the batch = where k_trace stored a hit record for it
+			if (lane_on) {
+				// RAY GENERATION, Renderer.hpp:113-127 (primary_ray with the pixel's part taken from the chunk set-up)
+				uint32_t rng = hash_2d(fp.acc_base + slot_it + 1u, pix_seed);
+				const float s0 = rand_unit_float(rng);
+				const float s1 = rand_unit_float(rng);
+				my_D = camera_ray_dir(fp.cam, pix_x, pix_y, s0, s1);
+				my_path = (slot_it << fp.pix_bits) | pix;
+				my_prim = prim_in[my_slot]; my_tfar = tfar_in[my_slot];          // the hit record of k_primary_hits / k_trace
+			}
+			if (++slot_it == slot_end) unit += gridDim.x;
+		} else {
+			lane_on = base + threadIdx.x < n;
 			const uint32_t nb = base + gridDim.x * kShadeBlock;
 			next_slot = (nb + threadIdx.x < n) ? queue_slot(qin, nb, nb + threadIdx.x) : 0u;
 			next_prim = prim_in[next_slot];
+			base = nb;
 		}
 		{
-			if (base + threadIdx.x < n) {
+			if (lane_on) {
 				const uint32_t i = my_slot;
 				const int32_t prim = my_prim;
 				if (prim < 0) {
 					// MISS SHADER, Renderer.hpp:408-420 (Q10: throughput.r scales all three channels)
 					f3 R{0.0f, 0.0f, 0.0f};
 					float thr_x = 1.0f;
-					uint32_t mpath; f3 md;
-					if (FIRST) primary_ray(fp, i, mpath, md.x, md.y, md.z);
-					else { R = { in.rr[i], in.rg[i], in.rb[i] }; thr_x = in.tr[i]; mpath = in.path[i]; }
+					uint32_t mpath = my_path; f3 md = my_D;
+					if (!FIRST) { R = { in.rr[i], in.rg[i], in.rb[i] }; thr_x = in.tr[i]; mpath = in.path[i]; }
 					if (sc.has_ambient) {
 						if (!FIRST) md = { in.dx[i], in.dy[i], in.dz[i] };
 						const f3 sky = sky_eval(sc, md.x, md.y, md.z);
@@ -1172,19 +1243,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		float light_distance = 0.0f;
 		if (FIRST ? is_hit : threadIdx.x < n_hits) {
 			const uint32_t i = FIRST ? my_slot : hit_list[threadIdx.x];
-			f3 D;
-			if (FIRST) primary_ray(fp, i, path, D.x, D.y, D.z);                  // bounce 0 has no stream: the ray is a function of its index
-			else { path = in.path[i]; D = { in.dx[i], in.dy[i], in.dz[i] }; }
+			f3 D = my_D;                                                       // bounce 0 has no stream: the ray is a function of its index (phase 1)
+			path = my_path;
+			if (!FIRST) { path = in.path[i]; D = { in.dx[i], in.dy[i], in.dz[i] }; }
 			float pdf_in = 0.0f;
 			if (!FIRST) {
 				R = { in.rr[i], in.rg[i], in.rb[i] };
 				thr = { in.tr[i], in.tg[i], in.tb[i] };
 				pdf_in = MIRT_INV_PI * max_sel(0.0f, D.z);                        // out->pdf of the bounce that sampled D (Q8), bit for bit
 			}
-			const int32_t prim = prim_in[i];
+			const int32_t prim = FIRST ? my_prim : prim_in[i];
 			{
 				// CLOSEST HIT SHADER, Renderer.hpp:169-214
-				const float depth = tfar_in[i];
+				const float depth = FIRST ? my_tfar : tfar_in[i];
 				const float4 hs = sc.spheres[prim];
 				const int32_t mat = sc.prim_mat[prim];
 				const f3 O = FIRST ? f3{ fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2] } : f3{ in.px[i], in.py[i], in.pz[i] };
@@ -1198,7 +1269,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 				const float4 alb = s_albedo[mat];
 				const bool is_emissive = max_sel(em.x, max_sel(em.y, em.z)) > MIRT_FLT_EPSILON;
 				const uint32_t acc = fp.acc_base + (path >> fp.pix_bits) + 1u;
-				const uint32_t seed = path_seed(fp, path & fp.pix_mask);
+				const uint32_t seed = FIRST ? pix_seed : path_seed(fp, path & fp.pix_mask);
 
 				// NEXT EVENT ESTIMATION, Renderer.hpp:247-298
 				if (fp.mis) {
@@ -1271,7 +1342,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneDev sc, FrameParams 
 		}
 		// ---- stream compaction: wave64 ballot + mbcnt prefix inside each wave, one atomic per workgroup and stream ----
 		uint32_t slot, sslot;
-		block_append2(survive, has_shadow, next_queue, shadow_queue, (base / kShadeBlock) % kSegs, append_scratch, parity, slot, sslot);
+		block_append2(survive, has_shadow, next_queue, shadow_queue, iteration % kSegs, append_scratch, parity, slot, sslot);
 		// (R + unoccluded NEE) + E is finished by k_trace's shadow_finish once the occlusion is known.  Non-emissive hits (E = +0)
 		// leave R where that result belongs and send a light record; the others send R and E along (kDestFull).
 		const bool direct = fp.idx_base != 0xffffffffu;                          // paths add straight into accumulator words that hold earlier samples

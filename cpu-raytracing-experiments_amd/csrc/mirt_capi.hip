@@ -149,7 +149,7 @@ uint32_t pix_bits_of(const mirt_ctx* c) { uint32_t b = 8; while ((1ull << b) < s
 // ... and a stream slot must stay below 2^30 as well (two flag bits in the words that carry it): pixels x slots + the padding of the kSegs queue segments
 uint32_t max_slots(const mirt_ctx* c) {
 	const uint64_t n_pix = std::max<uint64_t>(static_cast<uint64_t>(c->n_tiles) * kTileSize, 1);
-	const uint64_t by_slots = ((1ull << 30) - kSegs * kShadeBlock) / n_pix;
+	const uint64_t by_slots = ((1ull << 30) - 3ull * kSegs * kShadeBlock) / n_pix;
 	return static_cast<uint32_t>(std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(kMaxBatch, 1u << (30u - std::min<uint32_t>(pix_bits_of(c), 24u))), by_slots), 1));
 }
 uint32_t batch_floor(const mirt_ctx* c) { return std::max<uint32_t>(std::min<uint32_t>(c->policy.buckets, 5u), 1u); }   // the reference's natural group: five calls, five buckets
@@ -233,9 +233,10 @@ int ensure_streams(mirt_ctx* c) {
 	plan_batches(c);
 	const uint64_t cap64 = n_pix * batch_limit(c);
 	if (n_pix > (1u << 24)) return fail(c, MIRT_ERR_ARG, "more than 2^24 pixels per context (%llu); shard the tile range", (unsigned long long)n_pix);
-	if (cap64 + kSegs * kShadeBlock > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
+	if (cap64 + 3ull * kSegs * kShadeBlock > (1ull << 30)) return fail(c, MIRT_ERR_ARG, "stream capacity %llu too large", (unsigned long long)cap64);   // stream slots carry two flag bits (kDestAccum, kDestFull)
 	// a ray queue is kSegs segments of seg_cap slots (kernels.hpp "ray queues"): a plane holds kSegs * seg_cap entries
-	const uint32_t seg_cap = static_cast<uint32_t>(((cap64 + kShadeBlock - 1) / kShadeBlock + kSegs - 1) / kSegs * kShadeBlock);
+	// (+ 2 blocks: k_shade<FIRST> iterates pixel-major, and when the pixel count is an odd multiple of 256 its half-filled last chunk adds iterations)
+	const uint32_t seg_cap = static_cast<uint32_t>((((cap64 + kShadeBlock - 1) / kShadeBlock + kSegs - 1) / kSegs + 2) * kShadeBlock);
 	const uint32_t cap = seg_cap * kSegs;
 	const uint32_t nb = c->policy.max_bounces;
 	const uint32_t want = wanted_slots(c);
@@ -360,6 +361,7 @@ FrameParams frame_params(const mirt_ctx* c, uint32_t acc_base, uint32_t batch_n)
 	fp.buckets = c->policy.buckets;
 	fp.n_lights = c->scene.n_lights;
 	fp.mis = (c->policy.mis && c->scene.n_lights > 0) ? 1u : 0u;       // Q12 guard
+	fp.first_groups = 1;
 	fp.inv_n_pix = fp.n_pix ? 1.0f / static_cast<float>(fp.n_pix) : 0.0f;
 	fp.inv_h_tiles = fp.h_tiles ? 1.0f / static_cast<float>(fp.h_tiles) : 0.0f;
 	fp.inv_run_tiles = 1.0f / static_cast<float>(fp.run_tiles);
@@ -393,7 +395,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	uint32_t* work_next_shadow = work_next + nb;
 	uint32_t* fat_n_closest = work_next_shadow + nb;    // per-launch fat-ray counts (closest-hit list, shadow list)
 	uint32_t* fat_n_shadow = fat_n_closest + nb;
-	uint32_t* misc = fat_n_shadow + nb;                 // [0] work counter of k_primary_cand, [1] an unused fat-ray count
+	uint32_t* misc = fat_n_shadow + nb;                 // [0] work counter of k_primary_cand, [1] an unused fat-ray count, [2] pixels without a candidate list (their list: in.path of bounce 0)
 	// Camera rays of a batch go through per-pixel candidate lists when a pixel is sampled often enough to pay for its cone traversal
 	// (policy.trace_primary_rays = 1 switches that off: every primary ray then walks the tree; results are identical either way).
 	// (The half-angle bound assumes view.orient rotates: a non-unit quaternion, which the reference's View never holds (Camera.hpp:48-50),
@@ -412,7 +414,11 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t tgrid = trace_grid(c, total);
 	const uint32_t sgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * c->tune_shade_wgs));     // three 512-thread workgroups are resident per CU (k_shade: ~80 VGPRs); more only adds passes
 	const uint32_t tlds = trace_lds(c);
-	const uint32_t hgrid = static_cast<uint32_t>(std::min<uint64_t>((total + kShadeBlock - 1) / kShadeBlock, static_cast<uint64_t>(c->n_cu) * 4u));   // k_primary_hits: 28 VGPRs, no LDS: four 8-wave workgroups per CU
+	{	// k_shade<FIRST> hands out (512-pixel chunk, group of accumulations) pieces: at least ~8 per workgroup, so that a small image loads the grid evenly
+		const uint64_t n_chunks = (static_cast<uint64_t>(fp.n_pix) + kShadeBlock - 1) / kShadeBlock;
+		const uint64_t want = (8ull * sgrid + n_chunks - 1) / n_chunks;
+		fp.first_groups = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint64_t>(want, 1), batch_n));
+	}
 	// one workgroup per fat ray: a large scene (100 k spheres: ~100 us per ray) wants as many of them in flight as there are rays (a few hundred per launch)
 	const uint32_t fat_grid = sc.n_spheres > 4096 ? static_cast<uint32_t>(c->n_cu) * 2u : 64u;
 
@@ -431,20 +437,22 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const FatList fs{ fat_n_shadow + bounce, sl.fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 		  // the adds of bounce-1 that waited for occlusion land in stream `in` (= out of bounce-1) or the accumulator, before k_shade reads them
 		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, fp.pix_bits, nullptr };
+		  const Queue cq = (bounce == 0 && bundle) ? Queue{ misc + 2, 0u } : stream_queue(bounce);      // kPrimaryList: n[0] = listed pixels
 		  auto launch_trace = [&](auto kernel, auto fat_kernel) {
-		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, stream_queue(bounce), work_next + bounce,
+		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, cq, work_next + bounce,
 		                       sl.shadow_buf, sink, sq, sc_work, fc, fs, ctr);
 		    // the few rays too "fat" for the tree: brute force, one workgroup each
-		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr);
+		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr, misc + 2);
 		  };
 		  if (bounce == 0 && bundle) {
-		    // camera rays through per-pixel candidate lists (kernels.hpp kCollect): one cone traversal per pixel, then exact sphere tests
-		    // per sample; rays of pixels without a list come back in stream_queue(0) / in.path and are traced like any other ray
+		    // camera rays through per-pixel candidate lists (kernels.hpp kCollect): one cone traversal per pixel, then k_primary_hits intersects every
+		    // sample with its pixel's list.  Pixels without a list are listed in in.path (count: misc[2]) and all their samples traced like any other ray
 		    const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
-		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
-		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr);
-		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
-		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kShadeBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, in.path, stream_queue(0), ctr);
+		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr, in.path, misc + 2);
+		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr, in.path, misc + 2);
+		    const uint32_t hgrid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(fp.n_pix) + kBlock - 1) / kBlock, static_cast<uint64_t>(c->n_cu) * 64u));
+		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, ctr);
+		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, ctr);
 		    if (count) launch_trace((k_trace<true, kPrimaryList>), (k_trace_fat<true, kPrimaryList>)); else launch_trace((k_trace<false, kPrimaryList>), (k_trace_fat<false, kPrimaryList>));
 		  }
 		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
@@ -956,7 +964,7 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	{ Bracket t(c, MIRT_K_TRACE);                                               // policy.profile: the launch is timed like those of a batch (mirt_get_kernel_times)
 	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
 	                   Queue{ cn, 0u }, misc, ShadowBuf{}, ShadowSink{}, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr); }
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr, static_cast<const uint32_t*>(nullptr)); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
@@ -992,7 +1000,7 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	{ Bracket t(c, MIRT_K_TRACE);
 	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
 	                   Queue{ cn, 0u }, misc, sh, sink, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>()); }
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>(), static_cast<const uint32_t*>(nullptr)); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
@@ -1033,7 +1041,7 @@ int mirt_debug_primary_lists(mirt_ctx* c, uint32_t hist[10]) {
 	HIP_TRY(c, hipMemsetAsync(misc, 0, 64, c->stream));
 	const float rho = bundle_half_angle(c);
 	const FatList none{ misc + 1, sl.fat.as<uint32_t>(), 0u };
-	hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, c->counters.as<DevCounters>());
+	hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, c->counters.as<DevCounters>(), static_cast<uint32_t*>(nullptr), misc + 2);
 	HIP_TRY(c, hipGetLastError());
 	std::vector<uint32_t> host(static_cast<size_t>(fp.n_pix));                            // plane 0 of the lists: the counts
 	HIP_TRY(c, hipMemcpyAsync(host.data(), sl.cand.ptr, host.size() * 4, hipMemcpyDeviceToHost, c->stream));
