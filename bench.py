@@ -243,7 +243,7 @@ def main():
                     help="BASELINE config (default cfg4, the one the metric is quoted on). Every config keeps its own fixed image and splits its tile rows over the ranks")
     ap.add_argument("--spp", type=int, default=64, help="accumulations (Renderer::Accumulate() calls) per step")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
-    ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 512 M primary rays, at most 256 calls)")
+    ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 1 G primary rays, at most 256 calls)")
     ap.add_argument("--aux-steps", type=int, default=2, help="steps of the roofline passes (per-kernel HIP-event timing, counting replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the per-kernel timing and counting passes (roofline becomes null)")

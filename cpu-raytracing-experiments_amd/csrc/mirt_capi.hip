@@ -136,11 +136,11 @@ int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
 //   one eighth of cfg4:     16 x 3: 4367  32 x 3: 4981  64 x 3: 5103   64 x 1: 5498
 //   cfg3 1920x1088 S(10000): 16 x 3: 5378  32 x 3: 5753  64 x 3: 5700  64 x 1: 6354
 //   cfg2 1024^2 S(1000):    32 x 3: 7510  64 x 3: 8011  64 x 1: 7654
-// Hence: aim at 512 M primary rays per batch (at most max_slots() accumulations, at most what the free device memory holds), and keep
+// Hence: aim at 1 G primary rays per batch (round 2: 512 M; see kBatchRays) (at most max_slots() accumulations, at most what the free device memory holds), and keep
 // ONE batch in flight once a batch carries 96 M primary rays or more — launches that fill the chip for milliseconds gain
 // nothing from sharing it with another stream's kernels and lose to the interleaving — three below that (other batches fill the tails).
 constexpr uint32_t kMaxBatch = 256;         // upper limit of accumulations per batch; a context's own limit is what its path ids hold (max_slots)
-constexpr uint64_t kBatchRays = 512ull << 20;
+constexpr uint64_t kBatchRays = 1024ull << 20;   // round 3, cfg4 on the whole image (Mray/s, one batch in flight): 32 accumulations per batch 7970, 48: 8154, 63: 8218; 2 x 32: 7232, 2 x 24: 7192
 constexpr uint64_t kSerialRays = 96ull << 20;
 constexpr size_t kStreamPlanes = 2 * 13 + 2 + 17;      // two ray streams, hit (tfar, prim), shadow stream: 4-byte planes per ray of capacity
 // Path id = (batch slot << pix_bits) | local pixel, below 2^30 (bits 30 and 31 of the words that carry it are flags): a context that owns

@@ -77,7 +77,7 @@ typedef struct mirt_policy {
 	uint32_t profile;       /* 1: bracket every kernel launch with HIP events (mirt_get_kernel_times) */
 	uint32_t max_batch;     /* Accumulate() calls traced together as one batch: 1..256, clamped to what the context's path ids and stream slots hold —
 	                           2^30 / (its pixel count rounded up to a power of two), and pixels x batch + 12288 <= 2^30 (a context that owns all 2^24 pixels of a
-	                           4096 x 4096 image: 63); 0 = auto, about 512 M primary rays per batch within the free device memory.  mirt_get_policy
+	                           4096 x 4096 image: 63); 0 = auto, about 1 G primary rays per batch within the free device memory.  mirt_get_policy
 	                           reports the value in effect.  Results do not depend on it: adds reach every bucket in accumulation order. */
 	uint32_t reference_tree;/* 0 (default): traverse a GPU-internal SAH tree built over the same BVH-order prims; 1: traverse the caller's
 	                         * nodes as handed over.  Results are identical either way (DESIGN.md "Traversal semantics"); read at mirt_set_scene. */

@@ -951,7 +951,7 @@ def test_edit_protocol_scene_and_camera_changes(mirt):
 @pytest.mark.parametrize("name,n_tiles", [("cfg4", 8), ("cfg3", 10), ("cfg2", 10)])
 def test_bench_launch_shapes_vs_oracle(mirt, name, n_tiles):
     """The launch shapes bench.py's driver line is produced with, against the brute-force oracle: cfg4 4096x4096 as ONE
-    batch of 32 accumulations (path ids slot << 24 | pixel with slots up to 31, 537 M-entry stream planes, the contribution-buffer path);
+    batch of 63 accumulations (path ids slot << 24 | pixel with slots up to 62, 1.06 G-entry stream planes, the contribution-buffer path);
     cfg3 1920x1088 as one batch of the 192 accumulations of three 64-accumulation steps issued with AccumulateAsync; cfg2 1024x1024 as one
     batch of 256.  The oracle's cost is bounded by the number of tiles it renders (Oracle.Resize(w, h, tiles=...)), not by a smaller batch."""
     cfg = mirt.scene.CONFIGS[name]
@@ -964,8 +964,8 @@ def test_bench_launch_shapes_vs_oracle(mirt, name, n_tiles):
     r = mirt.Renderer(sc, max_bounces=mb, buckets=buckets, use_bvh=True); r.Resize(w, h)
     eff = r.get_policy()
     if name == "cfg4":
-        assert eff["max_batch"] == 32 and eff["streams"] == 1          # the plan bench.py logs: 512 M primary rays per batch, one batch in flight
-        spp = 32
+        assert eff["max_batch"] == 63 and eff["streams"] == 1          # the plan bench.py logs: 1 G primary rays per batch (what path ids and stream slots hold: 63), one batch in flight
+        spp = 63
         r.Accumulate(spp)
     elif name == "cfg3":
         assert eff["max_batch"] == 256 and eff["streams"] == 1
