@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate HIP streams (0 = library default, 3)")
     ap.add_argument("--max-batch", type=int, default=0, help="Accumulate() calls traced together as one batch (0 = library default: about 1 G primary rays, at most 256 calls)")
     ap.add_argument("--aux-steps", type=int, default=2, help="steps of the roofline passes (per-kernel HIP-event timing, counting replay)")
+    ap.add_argument("--gpu-build", action="store_true", help="policy.gpu_build: the traversal tree from the GPU LBVH builder instead of the host SAH sweep (measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true", help="skip the per-kernel timing and counting passes (roofline becomes null)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes")
@@ -303,7 +304,7 @@ def main():
     first_row, row_stride, n_rows = mirt.distributed.tile_rows(v_tiles, rank, world)     # interleaved tile rows: every rank sees sky and ground alike
     count = n_rows * h_tiles
 
-    r = make_renderer(mirt, cfg, local_rank, profile=False, streams=args.streams, max_batch=args.max_batch)
+    r = make_renderer(mirt, cfg, local_rank, profile=False, streams=args.streams, max_batch=args.max_batch, gpu_build=args.gpu_build)
     r.Resize(width, height)
     if world > 1:
         r.SetTileRows(first_row, row_stride)

@@ -13,9 +13,13 @@
 // child-pair records (f32 and binary16) exactly as the host layout does: leaf boxes grown by 2^-18 (max|c| + r) and
 // rounded outward, inner boxes unions, child with the larger half area first.
 //
-// A far outlier such as S(n)'s 1000-unit ground sphere takes the top Morton bit for itself and is split off at the
-// root, which is where a SAH builder puts it too.  Everywhere else the tree is what LBVH trees are: 1.3-2x the box tests
-// of the sweep-SAH tree built on the host — in exchange for milliseconds instead of 0.3 s per 100 k spheres.
+// The Morton grid is CUBIC and laid over the ordinary spheres only (round 3; round 2 normalised each axis by the bounds of all centres,
+// so S(n)'s 1000-unit ground sphere stretched the y axis to 1046 units for a 46-unit layer of spheres: y was first split where x and z
+// cells were already 6 units wide, and every node above that was a 46-unit column).  Spheres much larger than the typical one — radius
+// above 16 x the median radius' power of two, found with an exponent histogram — get a key bit of their own and are split off at the
+// root, which is where a SAH builder puts them too; the grid spans the centres of the others, with one cell size for the three axes.
+// What remains is what LBVH trees are: median splits of a space-filling curve instead of surface-area-guided ones — in exchange for
+// milliseconds instead of 0.1-0.3 s per 100 k spheres.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>
@@ -47,8 +51,8 @@ __device__ __forceinline__ float next_down(float x) { return -next_up(-x); }
 
 struct Box { float lo[3], hi[3]; };
 
-// Leaf boxes as in mirt_host::build_records, plus the bounds of the centres (ordered-uint atomics).
-__global__ __launch_bounds__(kBlock) void k_leaf_boxes(const float4* __restrict__ spheres, uint32_t n, Box* __restrict__ leaf_box, uint32_t* centre_bounds /* lo[3], hi[3] */) {
+// Leaf boxes as in mirt_host::build_records, plus a histogram of the radii's binary exponents (integer atomics: the same tree every run).
+__global__ __launch_bounds__(kBlock) void k_leaf_boxes(const float4* __restrict__ spheres, uint32_t n, Box* __restrict__ leaf_box, uint32_t* __restrict__ exp_hist /* [256] */) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n) return;
 	const float4 s = spheres[i];
@@ -62,10 +66,24 @@ __global__ __launch_bounds__(kBlock) void k_leaf_boxes(const float4* __restrict_
 	for (int a = 0; a < 3; a++) {
 		b.lo[a] = next_down((c[a] - r) - pad);
 		b.hi[a] = next_up((c[a] + r) + pad);
-		atomicMin(&centre_bounds[a], ordered_bits(c[a]));
-		atomicMax(&centre_bounds[3 + a], ordered_bits(c[a]));
 	}
 	leaf_box[i] = b;
+	atomicAdd(&exp_hist[(__float_as_uint(r) >> 23) & 0xffu], 1u);
+}
+// "Large" = radius of 16 x 2^(median exponent + 1) or more (one thread walks the 256 bins); then the bounds of the ordinary spheres' centres.
+__global__ void k_large_threshold(const uint32_t* __restrict__ exp_hist, uint32_t n, float* __restrict__ threshold) {
+	uint32_t seen = 0, e = 0;
+	for (; e < 256u; e++) { seen += exp_hist[e]; if (2u * seen >= n) break; }
+	const uint32_t te = e + 5u;                                              // 2^(e - 127 + 1) x 16
+	*threshold = te >= 255u ? __builtin_inff() : __uint_as_float(te << 23);
+}
+__global__ __launch_bounds__(kBlock) void k_centre_bounds(const float4* __restrict__ spheres, uint32_t n, const float* __restrict__ threshold, uint32_t* centre_bounds /* lo[3], hi[3] */) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const float4 s = spheres[i];
+	if (!(__builtin_sqrtf(s.w) < *threshold)) return;
+	const float c[3] = { s.x, s.y, s.z };
+	for (int a = 0; a < 3; a++) { atomicMin(&centre_bounds[a], ordered_bits(c[a])); atomicMax(&centre_bounds[3 + a], ordered_bits(c[a])); }
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {                // 10 bits -> every third bit
@@ -75,20 +93,22 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {                // 10 
 	v = (v * 0x00000005u) & 0x49249249u;
 	return v;
 }
-__global__ __launch_bounds__(kBlock) void k_morton(const float4* __restrict__ spheres, uint32_t n, const uint32_t* __restrict__ centre_bounds, uint64_t* __restrict__ keys) {
+__global__ __launch_bounds__(kBlock) void k_morton(const float4* __restrict__ spheres, uint32_t n, const uint32_t* __restrict__ centre_bounds, const float* __restrict__ threshold,
+                                                   uint64_t* __restrict__ keys) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n) return;
 	const float4 s = spheres[i];
 	const float c[3] = { s.x, s.y, s.z };
+	float lo[3], cell = 0.0f;                                                // one cell size for the three axes: the largest extent / 1024
+	for (int a = 0; a < 3; a++) { lo[a] = from_ordered(centre_bounds[a]); cell = fmaxf(cell, from_ordered(centre_bounds[3 + a]) - lo[a]); }
 	uint32_t q[3];
 	for (int a = 0; a < 3; a++) {
-		const float lo = from_ordered(centre_bounds[a]), hi = from_ordered(centre_bounds[3 + a]);
-		const float extent = hi - lo;
-		float u = extent > 0.0f ? (c[a] - lo) / extent : 0.0f;
-		u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+		float u = cell > 0.0f ? (c[a] - lo[a]) / cell : 0.0f;
+		u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);                         // (a large sphere's centre may lie far outside the grid)
 		q[a] = static_cast<uint32_t>(u);
 	}
-	const uint32_t code = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+	const uint32_t large = (__builtin_sqrtf(s.w) < *threshold) ? 0u : 1u;
+	const uint32_t code = (large << 30) | (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
 	keys[i] = (static_cast<uint64_t>(code) << 32) | i;                      // unique: ties broken by the prim index
 }
 
@@ -282,7 +302,7 @@ bool build_lbvh(hipStream_t st, const float4* spheres, uint32_t n, float* recs32
                 uint32_t* recs_wide, uint32_t* n_wide_out) {
 	if (n < 2) { if (err) *err = "fewer than two spheres"; return false; }
 	const uint32_t n_inner = n - 1;
-	Scratch leaf_box, inner_box, keys, keys_sorted, order_keys, order_sorted, c0, c1, par_inner, par_leaf, small, sort_tmp;
+	Scratch leaf_box, inner_box, keys, keys_sorted, order_keys, order_sorted, c0, c1, par_inner, par_leaf, small, sort_tmp, hist;
 	LBVH_TRY(leaf_box.get(sizeof(Box) * n)); LBVH_TRY(inner_box.get(sizeof(Box) * n_inner));
 	LBVH_TRY(keys.get(8ull * n)); LBVH_TRY(keys_sorted.get(8ull * n));
 	LBVH_TRY(order_keys.get(8ull * n_inner)); LBVH_TRY(order_sorted.get(8ull * n_inner));
@@ -293,18 +313,24 @@ bool build_lbvh(hipStream_t st, const float4* spheres, uint32_t n, float* recs32
 	uint32_t* centre_bounds = small.as<uint32_t>();
 	uint32_t* max_depth = centre_bounds + 6;
 	uint32_t* arrivals = centre_bounds + 8;
+	LBVH_TRY(hist.get(4ull * 260));                                         // 256 exponent bins + the threshold
+	uint32_t* exp_hist = hist.as<uint32_t>();
+	float* threshold = reinterpret_cast<float*>(exp_hist + 256);
+	LBVH_TRY(hipMemsetAsync(exp_hist, 0, 4ull * 260, st));
 	LBVH_TRY(hipMemsetAsync(centre_bounds, 0xff, 12, st));
 	LBVH_TRY(hipMemsetAsync(centre_bounds + 3, 0, 4ull * (5 + n_inner), st));
 	size_t tmp_bytes = 0, tmp2 = 0;
-	LBVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), static_cast<int>(n), 0, 62, st));
+	LBVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), static_cast<int>(n), 0, 63, st));
 	LBVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp2, order_keys.as<uint64_t>(), order_sorted.as<uint64_t>(), static_cast<int>(n_inner), 0, 40, st));
 	if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
 	LBVH_TRY(sort_tmp.get(tmp_bytes));
 
 	const dim3 gl((n + kBlock - 1) / kBlock), gi((n_inner + kBlock - 1) / kBlock), blk(kBlock);
-	hipLaunchKernelGGL(k_leaf_boxes, gl, blk, 0, st, spheres, n, leaf_box.as<Box>(), centre_bounds);
-	hipLaunchKernelGGL(k_morton, gl, blk, 0, st, spheres, n, centre_bounds, keys.as<uint64_t>());
-	LBVH_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), static_cast<int>(n), 0, 62, st));
+	hipLaunchKernelGGL(k_leaf_boxes, gl, blk, 0, st, spheres, n, leaf_box.as<Box>(), exp_hist);
+	hipLaunchKernelGGL(k_large_threshold, dim3(1), dim3(1), 0, st, exp_hist, n, threshold);
+	hipLaunchKernelGGL(k_centre_bounds, gl, blk, 0, st, spheres, n, threshold, centre_bounds);
+	hipLaunchKernelGGL(k_morton, gl, blk, 0, st, spheres, n, centre_bounds, threshold, keys.as<uint64_t>());
+	LBVH_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(), static_cast<int>(n), 0, 63, st));
 	hipLaunchKernelGGL(k_karras, gi, blk, 0, st, keys_sorted.as<uint64_t>(), n, c0.as<uint32_t>(), c1.as<uint32_t>(), par_inner.as<uint32_t>(), par_leaf.as<uint32_t>());
 	hipLaunchKernelGGL(k_inner_boxes, gl, blk, 0, st, keys_sorted.as<uint64_t>(), n, c0.as<uint32_t>(), c1.as<uint32_t>(), par_inner.as<uint32_t>(), par_leaf.as<uint32_t>(),
 	                   leaf_box.as<Box>(), inner_box.as<Box>(), arrivals);
