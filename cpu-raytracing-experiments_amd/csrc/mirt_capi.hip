@@ -263,8 +263,15 @@ int ensure_streams(mirt_ctx* c) {
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	for (PipeSlot& sl : c->slots) {
 		sl.in_use = false;
-		if (const hipError_t e = sl.arena.ensure(planes * plane_bytes); e != hipSuccess) {
-			// not enough device memory after all (someone else took it meanwhile): halve the automatic batch and plan again
+		hipError_t e = sl.arena.ensure(planes * plane_bytes);
+		const char* what = "ray streams";
+		if (e == hipSuccess) { e = sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)); what = "queue counters"; }
+		if (e == hipSuccess) { e = sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)); what = "fat-ray lists"; }
+		if (e == hipSuccess) { e = sl.cand.ensure(static_cast<size_t>(n_pix) * kCandStride * sizeof(uint32_t)); what = "candidate lists"; }
+		if (e == hipSuccess) { if (contrib) { e = sl.contrib.ensure(acc_bytes); what = "contribution buffer"; } else sl.contrib.release(); }
+		if (e != hipSuccess) {
+			// not enough device memory after all (someone else took it meanwhile — another context or process planning against the same
+			// free memory): halve the automatic batch and plan again
 			(void)hipGetLastError();
 			if (e == hipErrorOutOfMemory && !c->policy.max_batch && batch_limit(c) > batch_floor(c)) {
 				for (PipeSlot& other : c->slots) { other.arena.release(); other.contrib.release(); }
@@ -272,12 +279,8 @@ int ensure_streams(mirt_ctx* c) {
 				c->batch_mem_cap = std::max(batch_limit(c) / 2, batch_floor(c));
 				return ensure_streams(c);
 			}
-			return fail(c, MIRT_ERR_HIP, "ray streams (%zu bytes per batch in flight): %s", planes * plane_bytes, hipGetErrorString(e));
+			return fail(c, MIRT_ERR_HIP, "%s (%zu bytes of ray streams per batch in flight): %s", what, planes * plane_bytes, hipGetErrorString(e));
 		}
-		HIP_TRY(c, sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)));
-		HIP_TRY(c, sl.fat.ensure(2u * kFatCapacity * sizeof(uint32_t)));
-		HIP_TRY(c, sl.cand.ensure(static_cast<size_t>(n_pix) * kCandStride * sizeof(uint32_t)));
-		if (contrib) HIP_TRY(c, sl.contrib.ensure(acc_bytes)); else sl.contrib.release();
 		char* p = sl.arena.as<char>();
 		auto take = [&]() { void* r = p; p += plane_bytes; return r; };
 		for (int b = 0; b < 2; b++) {

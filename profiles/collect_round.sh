@@ -16,5 +16,8 @@ for C in cfg4 cfg3; do
 done
 # 4. one rank's share of the strong-scaled cfg4 image (what each GPU of an 8-GPU run does)
 step share 400 python profiles/experiments/rank_share.py 8 > $F/rank_share_8.txt 2> $F/share.err
-step rates 100 ./profiles/experiments/valu_rates > $F/valu_rates_raw.txt 2>&1
+# 5. the N > 1 line rehearsed on this box's one GPU (two ranks over gloo; rank 0's PMC share, CPU baseline, group host child) and bench.py --group
+step two_ranks 600 env MIRT_BENCH_SHARE_GPU=1 MIRT_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29731 bench.py --gpus 2 --steps 2 --warmup 1 > $F/bench_two_ranks_rehearsal.json 2> $F/two_ranks.err
+step group 300 env MIRT_BENCH_DEVICES=0,0 python bench.py --group --gpus 2 --steps 2 --warmup 1 > $F/bench_group_rehearsal.json 2> $F/group.err
+step gpu_build 300 python profiles/experiments/gpu_build.py > $F/gpu_build.txt 2>&1
 echo "collected"; head -c 600 $F/bench.json

@@ -12,7 +12,7 @@ import json
 try:
     d = json.load(open('gpurun_out/bench_cur.json')); r = d['roofline'] or {}
     print('cfg4 Mray/s %.1f  ms/step %.2f' % (d['value'], d['ms_per_step']), {k: round(v, 2) for k, v in (d['kernel_ms_per_step'] or {}).items()})
-    print('  valu frac', r.get('frac'), 'at clock', r.get('clock_GHz_during_k_trace'), r.get('frac_at_that_clock'), 'lane util', r.get('lane_utilisation'), 'valu/ray', r.get('valu_wave_instructions_per_traced_ray'), 'cyc/inst', r.get('simd_cycles_per_valu_instruction'), 'dual', r.get('dual_issue_share'))
+    print('  valu frac', r.get('frac'), 'at clock', r.get('clock_GHz_during_k_trace'), r.get('issue_frac_at_that_clock'), 'lane util', r.get('lane_utilisation'), 'valu/ray', r.get('valu_wave_instructions_per_traced_ray'), 'cyc/inst', r.get('simd_cycles_per_valu_instruction'), 'dual', r.get('dual_issue_share'))
     print('  lanes', r.get('lane_instructions', {}).get('frac'), 'mix', r.get('instruction_mix'), 'boxes', r.get('boxes_per_ray'), r.get('boxes_per_shadow_ray'))
     print('  hbm', {k: v for k, v in (r.get('hbm') or {}).items() if k != 'note'})
     print('  shade', {k: v for k, v in (r.get('shade') or {}).items() if k != 'note'})
