@@ -395,7 +395,9 @@ constexpr int kClosest = 0, kAnyHit = 1, kCollect = 2;
 //     covers the cone's reach and the reference's f32 discriminant error, origin outside.  F bounds every sample's first-hit
 //     distance on it from above, hence every sample's closest-hit distance: a sphere whose box starts beyond F cannot be a closest hit.
 // A pixel whose list would exceed kCandMax entries (silhouettes of many small spheres) is marked and its samples are traced normally.
-constexpr uint32_t kCandMax = 15, kCandStride = 16, kCandOverflow = 0xffffffffu;
+// (15 entries until round 3: 9 % of the cfg4 pixels overflowed; with 31 it is 3.8 % and the step 1 % faster — a sample of k_primary_hits reads its
+//  list from registers and L1 —; 63 entries buy nothing more.)
+constexpr uint32_t kCandMax = 31, kCandStride = 32, kCandOverflow = 0xffffffffu;
 struct Collect { uint32_t* cand; float rho; uint32_t n_pix; };      // cand[k * n_pix + pixel]: k = 0 the count, k = 1.. up to kCandMax BVH-order prim indices (plane-major: neighbouring pixels, neighbouring words)
 MIRT_DI void collect_leaf(bool on, float4 s, uint32_t prim, uint32_t pix, const Collect& col, Trav& t) {
 	uint32_t cnt = static_cast<uint32_t>(t.prim);

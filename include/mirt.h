@@ -263,7 +263,7 @@ int mirt_debug_math(mirt_ctx* ctx, int fn, size_t n, const float* in, float* out
  * bytes of a trace workgroup, out[6] trace workgroups per CU, out[7] CUs. */
 int mirt_debug_info(mirt_ctx* ctx, uint32_t out[8]);
 /* Length histogram of the per-pixel candidate lists of the current scene / camera / size (policy.trace_primary_rays = 0 path):
- * hist[n] = local pixels whose bundle of camera rays can hit n spheres for n = 0..7, hist[8] = 8 or more (lists hold up to 15), hist[9] = pixels without a list (traced normally). */
+ * hist[n] = local pixels whose bundle of camera rays can hit n spheres for n = 0..7, hist[8] = 8 or more (lists hold up to 31), hist[9] = pixels without a list (traced normally). */
 int mirt_debug_primary_lists(mirt_ctx* ctx, uint32_t hist[10]);
 /* Test knob: forbid (0) / allow (1, default) the binary16 records; takes effect at the next mirt_set_scene. */
 int mirt_debug_allow_half_boxes(mirt_ctx* ctx, int allow);
