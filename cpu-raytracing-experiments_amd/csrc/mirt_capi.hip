@@ -63,6 +63,9 @@ struct PipeSlot {
 	DeviceBuffer cand;               // per local pixel: candidate spheres of its bundle of camera rays (k_primary_cand), kCandStride words
 	hipEvent_t batch_done = nullptr; // recorded on `stream` after the batch's last kernel
 	hipEvent_t merged = nullptr;     // recorded on the main stream after the batch was merged (slot reusable)
+	hipEvent_t zeroed = nullptr;     // recorded on the side stream after the contribution buffer was zeroed again (one batch in flight)
+	bool contrib_is_zero = false;    // the whole contribution buffer holds +0 (or will, once `zeroed` has fired)
+	bool zero_pending = false;       // `zeroed` must be waited for before the next write into the buffer
 	bool in_use = false;
 	StreamBuf stream_buf[2]{};
 	ShadowBuf shadow_buf{};
@@ -76,6 +79,7 @@ struct mirt_ctx {
 	int device = 0;
 	int n_cu = 256;
 	hipStream_t stream = nullptr;
+	hipStream_t side_stream = nullptr;      // re-zeroes a contribution buffer while the next batch's camera-ray phase runs (launch_batch)
 	std::string error;
 
 	mirt_policy policy{ 16, 5, 1, 0, 0, 0, 0, 0, 0, 0, 0, { 0 } };     // RendererPolicy defaults, Renderer.hpp:19-26,41,71; USEBVH false BVH.hpp:307
@@ -111,7 +115,7 @@ struct mirt_ctx {
 	// launch-shape knobs for measurements (profiles/gpu_cycle.sh A/B runs), read from the environment at mirt_create: MIRT_TUNE_TRACE_WGS /
 	// MIRT_TUNE_SHADE_WGS = workgroups per CU, MIRT_TUNE_CHUNK = rays per work reservation, MIRT_TUNE_LEAF_BATCH = lanes at a leaf that
 	// trigger a leaf pass, MIRT_TUNE_REFILL_IDLE = idle lanes that trigger a refill.  They never change results.
-	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle, tune_wide = 1;
+	uint32_t tune_trace_wgs = 2, tune_shade_wgs = 3, tune_chunk = kChunkMax, tune_leaf_batch = kLeafBatch, tune_refill_idle = kRefillIdle, tune_wide = 1, tune_zero_ahead = 1;
 	// profiling
 	std::vector<TimedLaunch> pending;
 	std::vector<hipEvent_t> free_events;
@@ -196,6 +200,7 @@ uint32_t trace_grid(const mirt_ctx* c, uint64_t work_items) {
 
 hipError_t sync_all(mirt_ctx* c) {
 	for (PipeSlot& sl : c->slots) if (sl.stream) { hipError_t e = hipStreamSynchronize(sl.stream); if (e != hipSuccess) return e; }
+	if (c->side_stream) { hipError_t e = hipStreamSynchronize(c->side_stream); if (e != hipSuccess) return e; }
 	return hipStreamSynchronize(c->stream);
 }
 constexpr uint32_t kQueueWords = kSegs * kSegPitch;     // one ray queue's counters
@@ -249,6 +254,7 @@ int ensure_streams(mirt_ctx* c) {
 		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release(); sl.cand.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
+		if (sl.zeroed) (void)hipEventDestroy(sl.zeroed);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
 		c->slots.pop_back();
 	}
@@ -257,12 +263,13 @@ int ensure_streams(mirt_ctx* c) {
 		HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
 		HIP_TRY(c, hipEventCreateWithFlags(&sl.batch_done, hipEventDisableTiming));
 		HIP_TRY(c, hipEventCreateWithFlags(&sl.merged, hipEventDisableTiming));
+		HIP_TRY(c, hipEventCreateWithFlags(&sl.zeroed, hipEventDisableTiming));
 		c->slots.push_back(sl);
 	}
 	const size_t planes = kStreamPlanes;
 	const size_t plane_bytes = (static_cast<size_t>(cap) * 4 + 255) & ~static_cast<size_t>(255);
 	for (PipeSlot& sl : c->slots) {
-		sl.in_use = false;
+		sl.in_use = false; sl.contrib_is_zero = false; sl.zero_pending = false;      // (the caller has synchronised every stream)
 		hipError_t e = sl.arena.ensure(planes * plane_bytes);
 		const char* what = "ray streams";
 		if (e == hipSuccess) { e = sl.counts.ensure(counts_words(nb) * sizeof(uint32_t)); what = "queue counters"; }
@@ -426,7 +433,15 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 	const uint32_t fat_grid = sc.n_spheres > 4096 ? static_cast<uint32_t>(c->n_cu) * 2u : 64u;
 
 	if (pipelined && sl.in_use) HIP_TRY(c, hipStreamWaitEvent(st, sl.merged, 0));   // the slot's previous batch has been merged: buffers are free
-	if (contrib) HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, contrib_floats * sizeof(float), st));
+	// The contribution buffer must hold +0 where this batch's paths add.  With one batch in flight it is zeroed AHEAD of time: once a batch has been
+	// merged, the side stream clears what that batch dirtied (a prefix: [tile][slot][rgb][256] with the batch's slot count) while the next batch's
+	// camera-ray kernels, which do not touch it, run on the main stream (12.7 GB = 4 ms per 63-accumulation batch of cfg4 that no longer sit between
+	// two batches); k_shade of bounce 0, the first writer, waits for that.  Several batches in flight: zeroed in line, as before.
+	const bool zero_ahead = contrib && !pipelined && c->tune_zero_ahead;
+	if (contrib && !(zero_ahead && sl.contrib_is_zero)) {
+		HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, zero_ahead ? sl.contrib.bytes : contrib_floats * sizeof(float), st));
+		sl.contrib_is_zero = zero_ahead; sl.zero_pending = false;
+	}
 	HIP_TRY(c, hipMemsetAsync(counts, 0, counts_words(nb) * sizeof(uint32_t), st));
 	// bounce 0 has no ray stream: k_trace<PRIMARY> and k_shade<FIRST> derive the camera ray from its index (RAY GENERATION, Renderer.hpp:113-127)
 	for (uint32_t bounce = 0; bounce < nb; bounce++) {
@@ -460,6 +475,7 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  }
 		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
 		  else                  { if (count) launch_trace((k_trace<true, kPrimaryNone>), (k_trace_fat<true, kPrimaryNone>)); else launch_trace((k_trace<false, kPrimaryNone>), (k_trace_fat<false, kPrimaryNone>)); } }
+		if (bounce == 0 && zero_ahead && sl.zero_pending) { HIP_TRY(c, hipStreamWaitEvent(st, sl.zeroed, 0)); sl.zero_pending = false; }
 		{ Bracket t(c, MIRT_K_SHADE, st);
 		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr);
 		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr); }
@@ -476,6 +492,13 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		                     c->accumulator.as<float4>(), sl.contrib.as<float4>(), c->n_tiles, c->policy.buckets, batch_n, fp.acc_base); }
 		HIP_TRY(c, hipGetLastError());
 		if (pipelined) { HIP_TRY(c, hipEventRecord(sl.merged, c->stream)); sl.in_use = true; }
+		if (zero_ahead) {
+			HIP_TRY(c, hipEventRecord(sl.merged, c->stream));
+			HIP_TRY(c, hipStreamWaitEvent(c->side_stream, sl.merged, 0));
+			HIP_TRY(c, hipMemsetAsync(sl.contrib.ptr, 0, contrib_floats * sizeof(float), c->side_stream));
+			HIP_TRY(c, hipEventRecord(sl.zeroed, c->side_stream));
+			sl.zero_pending = true;                                              // contrib_is_zero stays true: it will be by the time anyone may write
+		}
 	}
 	c->batch_seq++;
 	c->accumulations += batch_n;
@@ -528,6 +551,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	c->device = device;
 	if (const char* e = std::getenv("MIRT_TUNE_CHUNK")) c->tune_chunk = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 64), 65536)) & ~63u;
 	if (const char* e = std::getenv("MIRT_TUNE_REFILL_IDLE")) c->tune_refill_idle = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
+	if (const char* e = std::getenv("MIRT_TUNE_ZERO_AHEAD")) c->tune_zero_ahead = std::atoi(e) != 0 ? 1u : 0u;
 	if (const char* e = std::getenv("MIRT_TUNE_WIDE")) c->tune_wide = std::atoi(e) != 0 ? 1u : 0u;
 	if (const char* e = std::getenv("MIRT_TUNE_LEAF_BATCH")) c->tune_leaf_batch = static_cast<uint32_t>(std::min(std::max(std::atoi(e), 1), 64));
 	if (const char* e = std::getenv("MIRT_TUNE_TRACE_WGS")) c->tune_trace_wgs = std::atoi(e) == 1 ? 1u : 2u;
@@ -535,6 +559,7 @@ int mirt_create(int device, mirt_ctx** out) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = c->counters.ensure(sizeof(DevCounters));
 	if (e == hipSuccess) e = hipMemsetAsync(c->counters.ptr, 0, sizeof(DevCounters), c->stream);
 	if (e != hipSuccess) { int r = fail(nullptr, MIRT_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete c; return r; }
@@ -551,6 +576,7 @@ int mirt_destroy(mirt_ctx* c) {
 		sl.arena.release(); sl.counts.release(); sl.contrib.release(); sl.fat.release(); sl.cand.release();
 		if (sl.batch_done) (void)hipEventDestroy(sl.batch_done);
 		if (sl.merged) (void)hipEventDestroy(sl.merged);
+		if (sl.zeroed) (void)hipEventDestroy(sl.zeroed);
 		if (sl.stream) (void)hipStreamDestroy(sl.stream);
 	}
 	c->slots.clear();
@@ -559,6 +585,7 @@ int mirt_destroy(mirt_ctx* c) {
 	                         &c->hdri, &c->accumulator, &c->framebuffer, &c->counters };
 	for (DeviceBuffer* b : bufs) b->release();
 	if (c->frame_host) (void)hipHostFree(c->frame_host);
+	if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return MIRT_OK;
