@@ -514,10 +514,26 @@ def main():
     r.close()                                              # every rank releases its GPU: streams, accumulator, scene
     if dist is not None:
         dist.barrier()
+    # While rank 0 runs the group host over ALL the node's devices, the other ranks wait on the rendezvous store (host side): an RCCL barrier
+    # would park a spinning kernel on every GPU the child is about to use.
+    store = None
+    if dist is not None and not args.no_group_host:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
     if rank == 0:
         if world > 1 and not args.no_group_host:
             out["group_host"] = group_host_child(args, world, log)
+            if store is not None:
+                store.set("mirt_group_host_done", "1")
         print(json.dumps(out), flush=True)
+    elif store is not None:
+        import datetime
+        try:
+            store.wait(["mirt_group_host_done"], datetime.timedelta(seconds=420))
+        except Exception:
+            pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
