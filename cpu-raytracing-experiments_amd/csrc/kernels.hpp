@@ -102,6 +102,9 @@ struct FrameParams {
 	uint32_t first_groups;      // k_shade<FIRST>: a chunk of 512 pixels x the batch's accumulations is handed out in this many pieces (small images: enough pieces for an even load)
 	float inv_n_pix, inv_h_tiles, inv_run_tiles;   // 1/n_pix, 1/h_tiles, 1/run_tiles for udiv_f (no integer division in the kernels)
 };
+// RayStream<>::Hit, DataStreams.hpp:90-111 (tfar, primID; matID is looked up by the shader): ONE 8-B record per ray, written by the lane that finished
+// the ray and read back by k_shade with one instruction each (two dword planes until round 3: two scattered 4-B stores and loads per ray).
+struct alignas(8) HitRec { float tfar; int32_t prim; };
 struct DevCounters {
 	unsigned long long rays, shadow_rays, nodes, spheres, shadow_nodes, shadow_spheres, terminated, dropped;
 };
@@ -898,7 +901,7 @@ MIRT_DI uint32_t primary_list_ray(const FrameParams& fp, const uint32_t* __restr
 }
 template <bool COUNT, int PRIMARY>
 __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FrameParams fp,
-                                                       StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out,
+                                                       StreamBuf in, HitRec* __restrict__ hit_out,
                                                        Queue closest_queue, uint32_t* closest_work,
                                                        ShadowBuf sh, ShadowSink sink,
                                                        Queue shadow_queue, uint32_t* shadow_work, FatList fat_closest, FatList fat_shadow,
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 				else { px = in.px[i]; py = in.py[i]; pz = in.pz[i]; dx = in.dx[i]; dy = in.dy[i]; dz = in.dz[i]; }
 				tf = MIRT_FLT_MAX;                                                 // hit reset, Renderer.hpp:150-158
 			};
-			auto store_result = [&](uint32_t i, const Trav& t, bool) { const uint32_t o = PRIMARY == kPrimaryList ? primary_list_ray(fp, in.path, n_ov, inv_n_ov, i) : i; tfar_out[o] = t.tfar; prim_out[o] = t.prim; };
+			auto store_result = [&](uint32_t i, const Trav& t, bool) { const uint32_t o = PRIMARY == kPrimaryList ? primary_list_ray(fp, in.path, n_ov, inv_n_ov, i) : i; hit_out[o] = HitRec{ t.tfar, t.prim }; };
 			trace_queue<kClosest, COUNT>(sc, tl, closest_queue, nc, closest_work, fat_closest, c_nodes, c_spheres, load_ray, store_result);
 		}
 		if (!PRIMARY) {
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 			float tfar = MIRT_FLT_MAX;             // hit reset, Renderer.hpp:150-158
 			int32_t prim = -1;
 			if (sc.use_bvh == 0) traverse_brute<false, COUNT>(sc, lds, active, px, py, pz, dx, dy, dz, tfar, prim, c_spheres);
-			if (active) { tfar_out[i] = tfar; prim_out[i] = prim; }
+			if (active) hit_out[i] = HitRec{ tfar, prim };
 		}
 		for (uint32_t base = blockIdx.x * kTraceBlock; base < ns; base += gridDim.x * kTraceBlock) {
 			const bool active = base + threadIdx.x < ns;
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_trace(SceneDev sc, FramePara
 // intersect_prims (BVH.hpp:236-288; closest = lexicographic minimum of (dist, prim index), i.e. the ascending strict-'<' scan)
 // for the closest-hit list, intersect_prims_shadow (BVH.hpp:290-305) for the shadow list.
 template <bool COUNT, int PRIMARY>
-__global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp, StreamBuf in, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, FatList fat_closest,
+__global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp, StreamBuf in, HitRec* __restrict__ hit_out, FatList fat_closest,
                                                     ShadowBuf sh, ShadowSink sink, FatList fat_shadow, DevCounters* ctr, const uint32_t* ov_count) {
 	__shared__ float s_t[16];
 	__shared__ int32_t s_p[16];
@@ -999,7 +1002,7 @@ __global__ __launch_bounds__(1024) void k_trace_fat(SceneDev sc, FrameParams fp,
 				const bool take = (op >= 0) && ((prim < 0) || (ot < tfar) || ((ot == tfar) && (op < prim)));
 				if (take) { tfar = ot; prim = op; }
 			}
-			tfar_out[i] = tfar; prim_out[i] = prim;
+			hit_out[i] = HitRec{ tfar, prim };
 			if (COUNT) atomicAdd(&ctr->spheres, static_cast<unsigned long long>(sc.n_spheres));
 		}
 	}
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(kTraceBlock, 8) void k_primary_cand(SceneDev sc, Fr
 // all their samples.
 constexpr uint32_t kCandRegs = 3;
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint32_t* __restrict__ cand, float* __restrict__ tfar_out, int32_t* __restrict__ prim_out, DevCounters* ctr) {
+__global__ __launch_bounds__(kBlock) void k_primary_hits(SceneDev sc, FrameParams fp, const uint32_t* __restrict__ cand, HitRec* __restrict__ hit_out, DevCounters* ctr) {
 	if (blockIdx.x == 0 && threadIdx.x == 0 && fp.n_pix) atomicAdd(&ctr->rays, static_cast<unsigned long long>(fp.n_pix) * fp.batch_n);     // Renderer.hpp:165: every camera ray of the batch
 	uint32_t c_spheres = 0;
 	const float ox = fp.cam.pos[0], oy = fp.cam.pos[1], oz = fp.cam.pos[2];
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_hits(SceneDev sc, FrameParam
 			}
 			if (COUNT) c_spheres += cnt;
 			const size_t i = static_cast<size_t>(slot) * fp.n_pix + pix;
-			tfar_out[i] = tfar; prim_out[i] = prim;
+			hit_out[i] = HitRec{ tfar, prim };
 		}
 	}
 	if (COUNT) wave_sum(c_spheres, &ctr->spheres);
@@ -1138,8 +1141,7 @@ MIRT_DI uint32_t block_compact(bool flag, uint32_t value, uint32_t* scratch, uin
 // (Measured and dropped twice: the candidate tests inside this kernel instead of k_primary_hits — ray-major in round 2, pixel-major in
 // round 3: at 6 waves per SIMD and 80 VGPRs the list's dependent loads cost k_shade<FIRST> 5 ms per cfg4 batch, as much as the kernel saved.)
 template <bool FIRST>
-__global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const float* __restrict__ tfar_in,
-                                                  const int32_t* __restrict__ prim_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
+__global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FrameParams fp, StreamBuf in, const HitRec* __restrict__ hit_in, StreamBuf out, ShadowBuf sh, uint32_t bounce,
                                                   Queue in_queue, Queue next_queue, Queue shadow_queue, float* __restrict__ accum, DevCounters* ctr) {
 	const QueueView qin = FIRST ? queue_identity(fp.n_pix * fp.batch_n) : queue_view(in_queue);
 	const uint32_t n = qin.pre[kSegs];
@@ -1161,7 +1163,7 @@ __global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FramePara
 	uint32_t next_slot = 0u; int32_t next_prim = -1;
 	if (!FIRST) {
 		next_slot = (blockIdx.x * kShadeBlock + threadIdx.x < n) ? queue_slot(qin, blockIdx.x * kShadeBlock, blockIdx.x * kShadeBlock + threadIdx.x) : 0u;
-		next_prim = prim_in[next_slot];
+		next_prim = hit_in[next_slot].prim;
 	}
 	// FIRST: the pixel of this lane in the chunk at hand, and what depends on it alone
 	uint32_t unit = blockIdx.x, chunk = 0u, slot_it = 0u, slot_end = 0u, pix = 0u, pix_seed = 0u;
@@ -1200,14 +1202,14 @@ __global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FramePara
 				const float s1 = rand_unit_float(rng);
 				my_D = camera_ray_dir(fp.cam, pix_x, pix_y, s0, s1);
 				my_path = (slot_it << fp.pix_bits) | pix;
-				my_prim = prim_in[my_slot]; my_tfar = tfar_in[my_slot];          // the hit record of k_primary_hits / k_trace
+				{ const HitRec h = hit_in[my_slot]; my_prim = h.prim; my_tfar = h.tfar; }      // the hit record of k_primary_hits / k_trace
 			}
 			if (++slot_it == slot_end) unit += gridDim.x;
 		} else {
 			lane_on = base + threadIdx.x < n;
 			const uint32_t nb = base + gridDim.x * kShadeBlock;
 			next_slot = (nb + threadIdx.x < n) ? queue_slot(qin, nb, nb + threadIdx.x) : 0u;
-			next_prim = prim_in[next_slot];
+			next_prim = hit_in[next_slot].prim;
 			base = nb;
 		}
 		{
@@ -1254,10 +1256,11 @@ __global__ __launch_bounds__(kShadeBlock, 6) void k_shade(SceneDev sc, FramePara
 				thr = { in.tr[i], in.tg[i], in.tb[i] };
 				pdf_in = MIRT_INV_PI * max_sel(0.0f, D.z);                        // out->pdf of the bounce that sampled D (Q8), bit for bit
 			}
-			const int32_t prim = FIRST ? my_prim : prim_in[i];
+			const HitRec hrec = FIRST ? HitRec{ my_tfar, my_prim } : hit_in[i];
+			const int32_t prim = hrec.prim;
 			{
 				// CLOSEST HIT SHADER, Renderer.hpp:169-214
-				const float depth = FIRST ? my_tfar : tfar_in[i];
+				const float depth = hrec.tfar;
 				const float4 hs = sc.spheres[prim];
 				const int32_t mat = sc.prim_mat[prim];
 				const f3 O = FIRST ? f3{ fp.cam.pos[0], fp.cam.pos[1], fp.cam.pos[2] } : f3{ in.px[i], in.py[i], in.pz[i] };

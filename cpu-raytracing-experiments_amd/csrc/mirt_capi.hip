@@ -69,8 +69,7 @@ struct PipeSlot {
 	bool in_use = false;
 	StreamBuf stream_buf[2]{};
 	ShadowBuf shadow_buf{};
-	float* hit_tfar = nullptr;
-	int32_t* hit_prim = nullptr;
+	HitRec* hit = nullptr;           // RayStream<>::Hit: one 8-B {tfar, primID} record per ray (two planes' worth of the arena)
 };
 
 } // namespace
@@ -298,7 +297,7 @@ int ensure_streams(mirt_ctx* c) {
 			s.rr = (float*)take(); s.rg = (float*)take(); s.rb = (float*)take();
 			s.path = (uint32_t*)take();
 		}
-		sl.hit_tfar = (float*)take(); sl.hit_prim = (int32_t*)take();
+		sl.hit = (HitRec*)take(); (void)take();                            // planes are adjacent: 8 B per ray
 		ShadowBuf& h = sl.shadow_buf;
 		h.px = (float*)take(); h.py = (float*)take(); h.pz = (float*)take();
 		h.dx = (float*)take(); h.dy = (float*)take(); h.dz = (float*)take(); h.tfar = (float*)take();
@@ -457,10 +456,10 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		  const ShadowSink sink{ in.rr, in.rg, in.rb, in.px, in.py, in.pz, accum, fp.idx_base, fp.idx_buckets, fp.pix_bits, nullptr };
 		  const Queue cq = (bounce == 0 && bundle) ? Queue{ misc + 2, 0u } : stream_queue(bounce);      // kPrimaryList: n[0] = listed pixels
 		  auto launch_trace = [&](auto kernel, auto fat_kernel) {
-		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, cq, work_next + bounce,
+		    hipLaunchKernelGGL(kernel, dim3(tgrid), dim3(kTraceBlock), tlds, st, sc, fp, in, sl.hit, cq, work_next + bounce,
 		                       sl.shadow_buf, sink, sq, sc_work, fc, fs, ctr);
 		    // the few rays too "fat" for the tree: brute force, one workgroup each
-		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, fc, sl.shadow_buf, sink, fs, ctr, misc + 2);
+		    if (sc.use_bvh) hipLaunchKernelGGL(fat_kernel, dim3(fat_grid), dim3(1024), 0, st, sc, fp, in, sl.hit, fc, sl.shadow_buf, sink, fs, ctr, misc + 2);
 		  };
 		  if (bounce == 0 && bundle) {
 		    // camera rays through per-pixel candidate lists (kernels.hpp kCollect): one cone traversal per pixel, then k_primary_hits intersects every
@@ -469,16 +468,16 @@ int launch_batch(mirt_ctx* c, uint32_t batch_n) {
 		    if (count) hipLaunchKernelGGL(k_primary_cand<true>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr, in.path, misc + 2);
 		    else       hipLaunchKernelGGL(k_primary_cand<false>, dim3(trace_grid(c, fp.n_pix)), dim3(kTraceBlock), tlds, st, sc, fp, sl.cand.as<uint32_t>(), rho, misc, none, ctr, in.path, misc + 2);
 		    const uint32_t hgrid = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(fp.n_pix) + kBlock - 1) / kBlock, static_cast<uint64_t>(c->n_cu) * 64u));
-		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, ctr);
-		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit_tfar, sl.hit_prim, ctr);
+		    if (count) hipLaunchKernelGGL(k_primary_hits<true>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit, ctr);
+		    else       hipLaunchKernelGGL(k_primary_hits<false>, dim3(hgrid), dim3(kBlock), 0, st, sc, fp, sl.cand.as<uint32_t>(), sl.hit, ctr);
 		    if (count) launch_trace((k_trace<true, kPrimaryList>), (k_trace_fat<true, kPrimaryList>)); else launch_trace((k_trace<false, kPrimaryList>), (k_trace_fat<false, kPrimaryList>));
 		  }
 		  else if (bounce == 0) { if (count) launch_trace((k_trace<true, kPrimaryAll>), (k_trace_fat<true, kPrimaryAll>)); else launch_trace((k_trace<false, kPrimaryAll>), (k_trace_fat<false, kPrimaryAll>)); }
 		  else                  { if (count) launch_trace((k_trace<true, kPrimaryNone>), (k_trace_fat<true, kPrimaryNone>)); else launch_trace((k_trace<false, kPrimaryNone>), (k_trace_fat<false, kPrimaryNone>)); } }
 		if (bounce == 0 && zero_ahead && sl.zero_pending) { HIP_TRY(c, hipStreamWaitEvent(st, sl.zeroed, 0)); sl.zero_pending = false; }
 		{ Bracket t(c, MIRT_K_SHADE, st);
-		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr);
-		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit_tfar, sl.hit_prim, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr); }
+		  if (bounce == 0) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr);
+		  else             hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kShadeBlock), 0, st, sc, fp, in, sl.hit, out, sl.shadow_buf, bounce, stream_queue(bounce), stream_queue(bounce + 1), shadow_queue(bounce), accum, ctr); }
 	}
 	HIP_TRY(c, hipGetLastError());
 	if (contrib) {
@@ -992,13 +991,14 @@ int mirt_debug_trace_closest(mirt_ctx* c, size_t n, const float* p_xyz, const fl
 	uint32_t* misc = cn + 2 * kQueueWords;
 	const FatList fc{ misc + 2, fat.as<uint32_t>(), kFatCapacity }, fs{ misc + 3, fat.as<uint32_t>() + kFatCapacity, kFatCapacity };
 	{ Bracket t(c, MIRT_K_TRACE);                                               // policy.profile: the launch is timed like those of a batch (mirt_get_kernel_times)
-	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n),
+	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, in, res.as<HitRec>(),
 	                   Queue{ cn, 0u }, misc, ShadowBuf{}, ShadowSink{}, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, scratch_ctr);
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<float>(), reinterpret_cast<int32_t*>(res.as<float>() + n), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr, static_cast<const uint32_t*>(nullptr)); }
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, in, res.as<HitRec>(), fc, ShadowBuf{}, ShadowSink{}, fs, scratch_ctr, static_cast<const uint32_t*>(nullptr)); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	if (e == hipSuccess) e = hipMemcpy(tfar_out, res.ptr, n * 4, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(prim_out, res.as<float>() + n, n * 4, hipMemcpyDeviceToHost);
+	std::vector<HitRec> host_hits(n);
+	if (e == hipSuccess) e = hipMemcpy(host_hits.data(), res.ptr, n * sizeof(HitRec), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) for (size_t i = 0; i < n; i++) { tfar_out[i] = host_hits[i].tfar; prim_out[i] = host_hits[i].prim; }
 	if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, "debug_trace_closest: %s", hipGetErrorString(e));
 	return MIRT_OK;
 }
@@ -1028,9 +1028,9 @@ int mirt_debug_trace_shadow(mirt_ctx* c, size_t n, const float* p_xyz, const flo
 	// the product's own kernels: the shadow queue of k_trace, then the fat-ray pass; the sink only records the occlusion flags
 	ShadowSink sink{}; sink.occ = occ.as<uint32_t>();
 	{ Bracket t(c, MIRT_K_TRACE);
-	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
+	hipLaunchKernelGGL((k_trace<false, kPrimaryNone>), dim3(trace_grid(c, n)), dim3(kTraceBlock), trace_lds(c), c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<HitRec*>(nullptr),
 	                   Queue{ cn, 0u }, misc, sh, sink, Queue{ cn + kQueueWords, 0u }, misc + 1, fc, fs, ctr.as<DevCounters>());
-	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>(), static_cast<const uint32_t*>(nullptr)); }
+	if (sc.use_bvh) hipLaunchKernelGGL((k_trace_fat<false, kPrimaryNone>), dim3(64), dim3(1024), 0, c->stream, sc, FrameParams{}, StreamBuf{}, static_cast<HitRec*>(nullptr), fc, sh, sink, fs, ctr.as<DevCounters>(), static_cast<const uint32_t*>(nullptr)); }
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	std::vector<uint32_t> host_occ(n);
